@@ -1,0 +1,300 @@
+"""ctypes binding of libbwt_hip.so (the C-ABI declared in include/bwt_hip.h).
+
+This is the Python-side view of the product for tests, the smoke test and the
+bench.  It contains no algorithm: every call goes to the HIP library, and
+importing it fails loudly when the library has not been built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbwt_hip.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class BwtHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bwt_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `make -C bwt_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.bwt_hip_last_error.restype = C.c_char_p
+    sig = {
+        "bwt_hip_create": [i32, C.POINTER(vp)],
+        "bwt_hip_set_text": [vp, _u8p, i64],
+        "bwt_hip_set_text_device": [vp, vp, i64],
+        "bwt_hip_gen_text": [vp, i64, C.c_uint64, i32],
+        "bwt_hip_get_text": [vp, _u8p],
+        "bwt_hip_leaf": [vp, i64, i64, i64, C.POINTER(vp)],
+        "bwt_hip_merge": [vp, vp, vp, i64, i64, C.POINTER(vp)],
+        "bwt_hip_rec": [vp, i64, i64, i64, i64, i64, C.POINTER(vp)],
+        "bwt_hip_pmbwt": [vp, i64, i64, i64, C.POINTER(vp)],
+        "bwt_hip_block_upload": [vp, i64, i64, _u8p, i64, i64, _i64p, _i64p, i64, C.POINTER(vp)],
+        "bwt_hip_block_info": [vp, _i64p, _i64p, _i64p, _i64p, C.POINTER(i32), _i64p],
+        "bwt_hip_block_get_L": [vp, vp, _u8p],
+        "bwt_hip_block_L_device": [vp, C.POINTER(vp)],
+        "bwt_hip_block_get_samples": [vp, vp, _i64p, _i64p, i64],
+        "bwt_hip_leaf_sa": [vp, i64, i64, _i64p],
+        "bwt_hip_block_init_extra": [vp, vp],
+        "bwt_hip_block_get_C": [vp, vp, i32, _i64p],
+        "bwt_hip_block_rank": [vp, vp, i64, _u8p, _i64p, _i64p],
+        "bwt_hip_block_LF": [vp, vp, i64, _u8p, _i64p, _i64p],
+        "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
+        "bwt_hip_set_timing": [vp, i32],
+        "bwt_hip_reset_timers": [vp],
+        "bwt_hip_timer_count": [vp],
+        "bwt_hip_timer_get": [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double), _i64p],
+        "bwt_hip_mem_stats": [vp, _i64p, _i64p, _i64p],
+        "bwt_hip_trim": [vp],
+        "bwt_hip_sync": [vp],
+        "bwt_hip_test_sort_u64": [vp, _u64p, _u32p, i64, i32, i32],
+        "bwt_hip_test_sort_u32": [vp, _u32p, _u32p, i64, i32, i32],
+        "bwt_hip_test_scan_u32": [vp, _u32p, i64, i32],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = i32
+    L.bwt_hip_destroy.argtypes = [vp]
+    L.bwt_hip_destroy.restype = None
+    L.bwt_hip_block_free.argtypes = [vp, vp]
+    L.bwt_hip_block_free.restype = None
+    L.bwt_hip_stream.argtypes = [vp]
+    L.bwt_hip_stream.restype = vp
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise BwtHipError(rc, lib().bwt_hip_last_error().decode("utf-8", "replace"))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Context:
+    """One GPU context; mirrors the lifetime of the reference's `mallocator mem` (src/pmbwt.cc:317-332)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().bwt_hip_create(device, C.byref(self._h)))
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().bwt_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- text -------------------------------------------------------------
+    def set_text(self, T):
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        _chk(lib().bwt_hip_set_text(self._h, _p(T, _u8p), len(T)))
+        self.n = len(T)
+
+    def set_text_device(self, ptr, n):
+        _chk(lib().bwt_hip_set_text_device(self._h, C.c_void_p(ptr), n))
+        self.n = n
+
+    def gen_text(self, n, seed=42, sigma=4):
+        _chk(lib().bwt_hip_gen_text(self._h, n, seed, sigma))
+        self.n = n
+
+    def get_text(self):
+        T = np.empty(self.n, dtype=np.uint8)
+        _chk(lib().bwt_hip_get_text(self._h, _p(T, _u8p)))
+        return T
+
+    # ---- pipeline ---------------------------------------------------------
+    def _blk(self, h):
+        return Block(self, h)
+
+    def leaf(self, a, b, ssa_n_samples):
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_leaf(self._h, a, b, ssa_n_samples, C.byref(h)))
+        return self._blk(h)
+
+    def merge(self, l, r, ssa_n_samples, build_gap_segment_sz=0):
+        h = C.c_void_p()
+        lh, rh = l._take(), r._take()
+        _chk(lib().bwt_hip_merge(self._h, lh, rh, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
+        return self._blk(h)
+
+    def rec(self, a, b, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz=0):
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_rec(self._h, a, b, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
+        return self._blk(h)
+
+    def pmbwt(self, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz=0):
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_pmbwt(self._h, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
+        return self._blk(h)
+
+    def upload_block(self, a, b, L, s_rank, e_rank, samp_rank, samp_pos):
+        L = np.ascontiguousarray(L, dtype=np.uint8)
+        sr = np.ascontiguousarray(samp_rank, dtype=np.int64)
+        sp = np.ascontiguousarray(samp_pos, dtype=np.int64)
+        assert len(L) == b - a
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_block_upload(self._h, a, b, _p(L, _u8p), s_rank, e_rank, _p(sr, _i64p), _p(sp, _i64p),
+                                        len(sr), C.byref(h)))
+        return self._blk(h)
+
+    def leaf_sa(self, a, b):
+        SA = np.empty(b - a, dtype=np.int64)
+        _chk(lib().bwt_hip_leaf_sa(self._h, a, b, _p(SA, _i64p)))
+        return SA
+
+    def gap(self, l, r, build_gap_segment_sz=0, want_gap=True, want_g=True):
+        gap = np.empty(l.b - l.a + 1, dtype=np.int64) if want_gap else None
+        g = np.empty(r.b - r.a, dtype=np.int64) if want_g else None
+        _chk(lib().bwt_hip_gap(self._h, l._h, r._h, build_gap_segment_sz, _p(gap, _i64p), _p(g, _i64p)))
+        return gap, g
+
+    # ---- observability ----------------------------------------------------
+    def set_timing(self, level):
+        _chk(lib().bwt_hip_set_timing(self._h, level))
+
+    def reset_timers(self):
+        _chk(lib().bwt_hip_reset_timers(self._h))
+
+    def timers(self):
+        """{phase: (milliseconds, algorithmic work, calls)}"""
+        out = {}
+        for i in range(lib().bwt_hip_timer_count(self._h)):
+            name, ms, work, calls = C.c_char_p(), C.c_double(), C.c_double(), C.c_int64()
+            _chk(lib().bwt_hip_timer_get(self._h, i, C.byref(name), C.byref(ms), C.byref(work), C.byref(calls)))
+            out[name.value.decode()] = (ms.value, work.value, calls.value)
+        return out
+
+    def mem_stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(lib().bwt_hip_mem_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"live": a.value, "peak": b.value, "reserved": c.value}
+
+    def trim(self):
+        _chk(lib().bwt_hip_trim(self._h))
+
+    def sync(self):
+        _chk(lib().bwt_hip_sync(self._h))
+
+    @property
+    def stream(self):
+        return lib().bwt_hip_stream(self._h)
+
+    # ---- primitives for unit tests ------------------------------------------
+    def test_sort(self, keys, vals=None, begin_bit=0, end_bit=None):
+        keys = np.ascontiguousarray(keys).copy()
+        vals = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        if keys.dtype == np.uint64:
+            _chk(lib().bwt_hip_test_sort_u64(self._h, _p(keys, _u64p), _p(vals, _u32p), len(keys), begin_bit,
+                                             64 if end_bit is None else end_bit))
+        else:
+            assert keys.dtype == np.uint32
+            _chk(lib().bwt_hip_test_sort_u32(self._h, _p(keys, _u32p), _p(vals, _u32p), len(keys), begin_bit,
+                                             32 if end_bit is None else end_bit))
+        return keys, vals
+
+    def test_scan(self, data, op):
+        d = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        _chk(lib().bwt_hip_test_scan_u32(self._h, _p(d, _u32p), len(d), op))
+        return d
+
+
+class Block:
+    """A partial BWT of T[a:b) in HBM: the fields of the reference's `struct bwt` (include/bwt.h:135-145)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+        a, b, s, e, n = (C.c_int64() for _ in range(5))
+        ec = C.c_int()
+        _chk(lib().bwt_hip_block_info(h, C.byref(a), C.byref(b), C.byref(s), C.byref(e), C.byref(ec), C.byref(n)))
+        self.a, self.b, self.s_rank, self.e_rank, self.e_char, self.n_samples = (
+            a.value, b.value, s.value, e.value, ec.value, n.value)
+
+    def _take(self):
+        h, self._h = self._h, None
+        return h
+
+    def free(self):
+        if self._h and self.ctx._h:
+            lib().bwt_hip_block_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def L(self):
+        """L[a:b) as a numpy array (index 0 is rank a)."""
+        out = np.empty(self.b - self.a, dtype=np.uint8)
+        _chk(lib().bwt_hip_block_get_L(self.ctx._h, self._h, _p(out, _u8p)))
+        return out
+
+    @property
+    def L_device(self):
+        p = C.c_void_p()
+        _chk(lib().bwt_hip_block_L_device(self._h, C.byref(p)))
+        return p.value
+
+    def samples(self):
+        r = np.empty(self.n_samples, dtype=np.int64)
+        p = np.empty(self.n_samples, dtype=np.int64)
+        _chk(lib().bwt_hip_block_get_samples(self.ctx._h, self._h, _p(r, _i64p), _p(p, _i64p), self.n_samples))
+        return r, p
+
+    def init_extra(self):
+        _chk(lib().bwt_hip_block_init_extra(self.ctx._h, self._h))
+
+    def C(self, alpha_max):
+        out = np.empty(alpha_max + 1, dtype=np.int64)
+        _chk(lib().bwt_hip_block_get_C(self.ctx._h, self._h, alpha_max, _p(out, _i64p)))
+        return out
+
+    def rank(self, sym, pos):
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        out = np.empty(len(sym), dtype=np.int64)
+        _chk(lib().bwt_hip_block_rank(self.ctx._h, self._h, len(sym), _p(sym, _u8p), _p(pos, _i64p), _p(out, _i64p)))
+        return out
+
+    def LF(self, sym, rank):
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        rank = np.ascontiguousarray(rank, dtype=np.int64)
+        out = np.empty(len(sym), dtype=np.int64)
+        _chk(lib().bwt_hip_block_LF(self.ctx._h, self._h, len(sym), _p(sym, _u8p), _p(rank, _i64p), _p(out, _i64p)))
+        return out

@@ -1,0 +1,556 @@
+// The extern "C" boundary (declared in include/bwt_hip.h).  Thin: argument
+// checks, exception -> status conversion, host<->device staging.
+#include <string.h>
+
+#include <memory>
+
+#include "../../include/bwt_hip.h"
+#include "internal.h"
+
+using namespace bwtamd;
+
+struct bwt_hip_ctx {
+  Ctx c;
+};
+struct bwt_hip_block {
+  Block b;
+};
+
+static thread_local std::string g_last_error;
+
+const char *bwt_hip_last_error(void) { return g_last_error.c_str(); }
+
+#define API_BEGIN try {
+#define API_END                                  \
+  }                                              \
+  catch (const Error &e) {                       \
+    g_last_error = e.what();                     \
+    return e.code ? e.code : BWT_HIP_EINTERNAL;  \
+  }                                              \
+  catch (const std::exception &e) {              \
+    g_last_error = e.what();                     \
+    return BWT_HIP_EINTERNAL;                    \
+  }                                              \
+  return 0;
+
+static void need(bool cond, const char *what) {
+  if (!cond) fail(BWT_HIP_EINVAL, "invalid argument: %s", what);
+}
+
+static Block *as_block(bwt_hip_block *b) { return reinterpret_cast<Block *>(b); }
+static const Block *as_block(const bwt_hip_block *b) { return reinterpret_cast<const Block *>(b); }
+static bwt_hip_block *as_handle(Block *b) { return reinterpret_cast<bwt_hip_block *>(b); }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+int bwt_hip_create(int device, bwt_hip_ctx **out) {
+  API_BEGIN
+  need(out != nullptr, "out");
+  int count = 0;
+  HIP_CHECK(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) fail(BWT_HIP_EINVAL, "device %d out of range (%d visible)", device, count);
+  HIP_CHECK(hipSetDevice(device));
+  std::unique_ptr<bwt_hip_ctx> h(new bwt_hip_ctx());
+  Ctx &c = h->c;
+  c.device = device;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    fail(BWT_HIP_EINVAL, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  c.n_cu = prop.multiProcessorCount;
+  HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  HIP_CHECK(hipHostMalloc((void **)&c.h_scalars, 64 * sizeof(u32), hipHostMallocDefault));
+  HIP_CHECK(hipMalloc((void **)&c.d_scalars, 64 * sizeof(u32)));
+  *out = h.release();
+  API_END
+}
+
+void bwt_hip_destroy(bwt_hip_ctx *ctx) {
+  if (!ctx) return;
+  Ctx &c = ctx->c;
+  (void)hipSetDevice(c.device);
+  (void)hipStreamSynchronize(c.stream);
+  for (auto &p : c.pending) {
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  for (auto e : c.event_pool) (void)hipEventDestroy(e);
+  for (auto &kv : c.free_blocks) (void)hipFree(kv.second);
+  for (auto &kv : c.live_blocks) (void)hipFree(kv.first);
+  if (c.h_scalars) (void)hipHostFree(c.h_scalars);
+  if (c.d_scalars) (void)hipFree(c.d_scalars);
+  (void)hipStreamDestroy(c.stream);
+  delete ctx;
+}
+
+static void drop_text(Ctx &c) {
+  if (c.T_owned) c.release(c.T_owned);
+  c.T_owned = nullptr;
+  c.T = nullptr;
+  c.n = 0;
+}
+
+static void adopt_text(Ctx &c, const u8 *dT, i64 n) {
+  int max_sym = 0, last = 0;
+  i64 n_zero = 0;
+  text_stats(c, dT, n, &max_sym, &n_zero, &last);
+  if (last != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", last);
+  if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
+  c.T = dT;
+  c.n = n;
+  c.max_sym = max_sym;
+  int bits = 1;
+  while ((max_sym >> bits) != 0) bits++;
+  c.sym_bits = bits;
+}
+
+static void check_n(i64 n) {
+  if (n < 1) fail(BWT_HIP_EINVAL, "n must be at least 1");
+  if ((u64)n > 0xFFFFFFFFull - 3) fail(BWT_HIP_EINVAL, "n = %ld exceeds 2^32 - 4", (long)n);
+}
+
+int bwt_hip_set_text(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n) {
+  API_BEGIN
+  need(ctx && T_host, "ctx, T_host");
+  check_n(n);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  drop_text(c);
+  c.T_owned = (u8 *)c.alloc((size_t)n + 64);
+  HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
+  HIP_CHECK(hipMemcpyAsync(c.T_owned, T_host, (size_t)n, hipMemcpyHostToDevice, c.stream));
+  c.sync();
+  try {
+    adopt_text(c, c.T_owned, n);
+  } catch (...) {
+    drop_text(c);
+    throw;
+  }
+  API_END
+}
+
+int bwt_hip_set_text_device(bwt_hip_ctx *ctx, const uint8_t *T_dev, int64_t n) {
+  API_BEGIN
+  need(ctx && T_dev, "ctx, T_dev");
+  need(((uintptr_t)T_dev & 15) == 0, "T_dev must be 16-byte aligned");
+  check_n(n);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  drop_text(c);
+  adopt_text(c, T_dev, n);
+  API_END
+}
+
+int bwt_hip_gen_text(bwt_hip_ctx *ctx, int64_t n, uint64_t seed, int sigma) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  need(sigma >= 1 && sigma <= 255, "sigma in 1..255");
+  check_n(n);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  drop_text(c);
+  c.T_owned = (u8 *)c.alloc((size_t)n + 64);
+  HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
+  device_gen_text(c, c.T_owned, n, seed, sigma);
+  try {
+    adopt_text(c, c.T_owned, n);
+  } catch (...) {
+    drop_text(c);
+    throw;
+  }
+  API_END
+}
+
+int bwt_hip_get_text(bwt_hip_ctx *ctx, uint8_t *T_host) {
+  API_BEGIN
+  need(ctx && T_host, "ctx, T_host");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  HIP_CHECK(hipMemcpyAsync(T_host, c.T, (size_t)c.n, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  API_END
+}
+
+// ---------------------------------------------------------------------------
+// pipeline
+// ---------------------------------------------------------------------------
+static Block *do_leaf(Ctx &c, i64 a, i64 b, i64 ns) {
+  DBuf<u32> sa = leaf_suffix_array(c, a, b);
+  return leaf_from_sa(c, a, b, sa.get(), ns);
+}
+
+static Block *do_merge(Ctx &c, Block *l, Block *r, i64 ns, i64 seg) {
+  std::unique_ptr<Block> L(l), R(r);
+  GapResult gap = build_gap(c, *l, *r, seg, false);
+  return merge_blocks(c, *l, *r, gap, ns);
+}
+
+static Block *do_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg) {
+  if (b - a <= th || b - a < 2) return do_leaf(c, a, b, ns);
+  i64 mid = (a + b) / 2;
+  std::unique_ptr<Block> l(do_rec(c, a, mid, th, ns, seg));
+  std::unique_ptr<Block> r(do_rec(c, mid, b, th, ns, seg));
+  return do_merge(c, l.release(), r.release(), ns, seg);
+}
+
+int bwt_hip_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ns, bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && out, "ctx, out");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  *out = as_handle(do_leaf(ctx->c, a, b, ns));
+  API_END
+}
+
+int bwt_hip_merge(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t ns, int64_t seg,
+                  bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && l && r && out, "ctx, l, r, out");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  *out = as_handle(do_merge(ctx->c, as_block(l), as_block(r), ns, seg));
+  API_END
+}
+
+int bwt_hip_rec(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t th, int64_t ns, int64_t seg, bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && out, "ctx, out");
+  need(ctx->c.T != nullptr, "no text set");
+  need(a >= 0 && a < b && b <= ctx->c.n, "0 <= a < b <= n");
+  need(th >= 1, "bwt_rec_threshold >= 1");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  *out = as_handle(do_rec(ctx->c, a, b, th, ns, seg));
+  API_END
+}
+
+int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t th, int64_t ns, int64_t seg, bwt_hip_block **out) {
+  if (!ctx) {
+    g_last_error = "invalid argument: ctx";
+    return BWT_HIP_EINVAL;
+  }
+  return bwt_hip_rec(ctx, 0, ctx->c.n, th, ns, seg, out);
+}
+
+int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *L_host, int64_t s_rank,
+                         int64_t e_rank, const int64_t *samp_rank, const int64_t *samp_pos, int64_t ns,
+                         bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && L_host && out, "ctx, L_host, out");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  need(a >= 0 && a < b && b <= c.n, "0 <= a < b <= n");
+  need(s_rank >= a && s_rank < b && e_rank >= a && e_rank < b, "ranks inside [a,b)");
+  need(ns >= 1 && samp_rank && samp_pos, "samples");
+  HIP_CHECK(hipSetDevice(c.device));
+  std::unique_ptr<Block> blk(new Block());
+  blk->a = a;
+  blk->b = b;
+  blk->s_rank = s_rank - a;
+  blk->e_rank = e_rank - a;
+  blk->L = DBuf<u8>(c, (size_t)(b - a));
+  blk->samp_rank = DBuf<u32>(c, (size_t)ns);
+  blk->samp_pos = DBuf<u32>(c, (size_t)ns);
+  blk->n_samp = ns;
+  std::vector<u32> hr((size_t)ns), hp((size_t)ns);
+  for (i64 k = 0; k < ns; k++) {
+    need(samp_rank[k] >= a && samp_rank[k] < b && samp_pos[k] >= a && samp_pos[k] < b, "sample inside [a,b)");
+    need(k == 0 || samp_pos[k] > samp_pos[k - 1], "samples ordered by pos");
+    hr[(size_t)k] = (u32)(samp_rank[k] - a);
+    hp[(size_t)k] = (u32)samp_pos[k];
+  }
+  HIP_CHECK(hipMemcpyAsync(blk->L.get(), L_host, (size_t)(b - a), hipMemcpyHostToDevice, c.stream));
+  HIP_CHECK(hipMemcpyAsync(blk->samp_rank.get(), hr.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c.stream));
+  HIP_CHECK(hipMemcpyAsync(blk->samp_pos.get(), hp.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c.stream));
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  blk->e_char = *(u8 *)c.h_scalars;
+  *out = as_handle(blk.release());
+  API_END
+}
+
+void bwt_hip_block_free(bwt_hip_ctx *ctx, bwt_hip_block *blk) {
+  (void)ctx;
+  delete as_block(blk);
+}
+
+// ---------------------------------------------------------------------------
+// reading a block
+// ---------------------------------------------------------------------------
+int bwt_hip_block_info(const bwt_hip_block *blk_, int64_t *a, int64_t *b, int64_t *s_rank, int64_t *e_rank,
+                       int *e_char, int64_t *n_samples) {
+  API_BEGIN
+  need(blk_ != nullptr, "blk");
+  const Block *blk = as_block(blk_);
+  if (a) *a = blk->a;
+  if (b) *b = blk->b;
+  if (s_rank) *s_rank = blk->a + blk->s_rank;
+  if (e_rank) *e_rank = blk->a + blk->e_rank;
+  if (e_char) *e_char = blk->e_char;
+  if (n_samples) *n_samples = blk->n_samp;
+  API_END
+}
+
+int bwt_hip_block_get_L(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, uint8_t *L_host) {
+  API_BEGIN
+  need(ctx && blk_ && L_host, "ctx, blk, L_host");
+  const Block *blk = as_block(blk_);
+  HIP_CHECK(hipMemcpyAsync(L_host, blk->L.get(), (size_t)blk->len(), hipMemcpyDeviceToHost, ctx->c.stream));
+  ctx->c.sync();
+  API_END
+}
+
+int bwt_hip_block_L_device(const bwt_hip_block *blk_, const uint8_t **L_dev) {
+  API_BEGIN
+  need(blk_ && L_dev, "blk, L_dev");
+  *L_dev = as_block(blk_)->L.get();
+  API_END
+}
+
+int bwt_hip_block_get_samples(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, int64_t *rank_out, int64_t *pos_out,
+                              int64_t cap) {
+  API_BEGIN
+  need(ctx && blk_ && rank_out && pos_out, "ctx, blk, rank_out, pos_out");
+  const Block *blk = as_block(blk_);
+  i64 k = blk->n_samp < cap ? blk->n_samp : cap;
+  if (k > 0) {
+    std::vector<u32> hr((size_t)k), hp((size_t)k);
+    HIP_CHECK(hipMemcpyAsync(hr.data(), blk->samp_rank.get(), (size_t)k * 4, hipMemcpyDeviceToHost, ctx->c.stream));
+    HIP_CHECK(hipMemcpyAsync(hp.data(), blk->samp_pos.get(), (size_t)k * 4, hipMemcpyDeviceToHost, ctx->c.stream));
+    ctx->c.sync();
+    for (i64 i = 0; i < k; i++) {
+      rank_out[i] = blk->a + (i64)hr[(size_t)i];
+      pos_out[i] = (i64)hp[(size_t)i];
+    }
+  }
+  API_END
+}
+
+// ---------------------------------------------------------------------------
+// taps
+// ---------------------------------------------------------------------------
+int bwt_hip_leaf_sa(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t *SA_host) {
+  API_BEGIN
+  need(ctx && SA_host, "ctx, SA_host");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  DBuf<u32> sa = leaf_suffix_array(c, a, b);
+  std::vector<u32> h((size_t)(b - a));
+  HIP_CHECK(hipMemcpyAsync(h.data(), sa.get(), h.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  for (size_t i = 0; i < h.size(); i++) SA_host[i] = (i64)h[i];
+  API_END
+}
+
+int bwt_hip_block_init_extra(bwt_hip_ctx *ctx, bwt_hip_block *blk) {
+  API_BEGIN
+  need(ctx && blk, "ctx, blk");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  build_wavelet(ctx->c, *as_block(blk));
+  API_END
+}
+
+int bwt_hip_block_get_C(bwt_hip_ctx *ctx, bwt_hip_block *blk_, int alpha_max, int64_t *C_out) {
+  API_BEGIN
+  need(ctx && blk_ && C_out, "ctx, blk, C_out");
+  need(alpha_max >= 0 && alpha_max <= 255, "alpha_max in 0..255");
+  Block *blk = as_block(blk_);
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  count_alphabets(ctx->c, *blk);
+  if (ctx->c.max_sym > alpha_max)
+    fail(BWT_HIP_ETEXT, "text holds symbol %d above alpha_max %d", ctx->c.max_sym, alpha_max);
+  for (int k = 0; k <= alpha_max; k++) C_out[k] = blk->C[k];
+  API_END
+}
+
+static void run_rank(Ctx &c, Block &blk, i64 nq, const uint8_t *sym, const int64_t *pos, int64_t *out, bool lf) {
+  if (nq <= 0) return;
+  const i64 m = blk.len();
+  std::vector<u32> hp((size_t)nq);
+  for (i64 k = 0; k < nq; k++) {
+    i64 p = lf ? pos[k] - blk.a : pos[k];
+    if (p < 0 || p > m) fail(BWT_HIP_EINVAL, "query %ld: position %ld outside the block", (long)k, (long)pos[k]);
+    if ((int)sym[k] >> c.sym_bits) fail(BWT_HIP_EINVAL, "query %ld: symbol %d not in the text's alphabet", (long)k, (int)sym[k]);
+    hp[(size_t)k] = (u32)p;
+  }
+  DBuf<u8> ds(c, (size_t)nq);
+  DBuf<u32> dp(c, (size_t)nq), dout(c, (size_t)nq);
+  HIP_CHECK(hipMemcpyAsync(ds.get(), sym, (size_t)nq, hipMemcpyHostToDevice, c.stream));
+  HIP_CHECK(hipMemcpyAsync(dp.get(), hp.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c.stream));
+  rank_batch(c, blk, ds.get(), dp.get(), dout.get(), (size_t)nq, lf);
+  HIP_CHECK(hipMemcpyAsync(hp.data(), dout.get(), (size_t)nq * 4, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  for (i64 k = 0; k < nq; k++) out[k] = (i64)hp[(size_t)k] + (lf ? blk.a : 0);
+}
+
+int bwt_hip_block_rank(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uint8_t *sym, const int64_t *pos,
+                       int64_t *out) {
+  API_BEGIN
+  need(ctx && blk && sym && pos && out, "ctx, blk, sym, pos, out");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  run_rank(ctx->c, *as_block(blk), nq, sym, pos, out, false);
+  API_END
+}
+
+int bwt_hip_block_LF(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uint8_t *sym, const int64_t *rank,
+                     int64_t *out) {
+  API_BEGIN
+  need(ctx && blk && sym && rank && out, "ctx, blk, sym, rank, out");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  run_rank(ctx->c, *as_block(blk), nq, sym, rank, out, true);
+  API_END
+}
+
+int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l_, bwt_hip_block *r_, int64_t seg, int64_t *gap_out,
+                int64_t *g_out) {
+  API_BEGIN
+  need(ctx && l_ && r_, "ctx, l, r");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  Block &l = *as_block(l_), &r = *as_block(r_);
+  GapResult G = build_gap(c, l, r, seg, g_out != nullptr);
+  const size_t m = (size_t)l.len(), rn = (size_t)r.len();
+  if (gap_out) {
+    std::vector<u32> S(m + 1);
+    HIP_CHECK(hipMemcpyAsync(S.data(), G.S.get(), (m + 1) * 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    for (size_t i = 0; i <= m; i++) gap_out[i] = (i64)S[i] - (i ? (i64)S[i - 1] : 0);
+  }
+  if (g_out) {
+    std::vector<u32> g(rn);
+    HIP_CHECK(hipMemcpyAsync(g.data(), G.g_text.get(), rn * 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    for (size_t j = 0; j < rn; j++) g_out[j] = l.a + (i64)g[j];
+  }
+  API_END
+}
+
+// ---------------------------------------------------------------------------
+// observability
+// ---------------------------------------------------------------------------
+int bwt_hip_set_timing(bwt_hip_ctx *ctx, int level) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  ctx->c.flush_timers();
+  ctx->c.timing_level = level;
+  API_END
+}
+
+int bwt_hip_reset_timers(bwt_hip_ctx *ctx) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  ctx->c.flush_timers();
+  for (auto &t : ctx->c.timers) {
+    t.ms = 0;
+    t.bytes = 0;
+    t.launches = 0;
+  }
+  API_END
+}
+
+int bwt_hip_timer_count(bwt_hip_ctx *ctx) {
+  if (!ctx) return 0;
+  try {
+    ctx->c.flush_timers();
+  } catch (...) {
+  }
+  return (int)ctx->c.timers.size();
+}
+
+int bwt_hip_timer_get(bwt_hip_ctx *ctx, int idx, const char **name, double *ms, double *work, int64_t *calls) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  need(idx >= 0 && idx < (int)ctx->c.timers.size(), "idx");
+  const PhaseTimer &t = ctx->c.timers[(size_t)idx];
+  if (name) *name = t.name.c_str();
+  if (ms) *ms = t.ms;
+  if (work) *work = t.bytes;
+  if (calls) *calls = t.launches;
+  API_END
+}
+
+int bwt_hip_mem_stats(bwt_hip_ctx *ctx, int64_t *live, int64_t *peak, int64_t *reserved) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  if (live) *live = (i64)ctx->c.bytes_live;
+  if (peak) *peak = (i64)ctx->c.bytes_peak;
+  if (reserved) *reserved = (i64)ctx->c.bytes_reserved;
+  API_END
+}
+
+int bwt_hip_trim(bwt_hip_ctx *ctx) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  ctx->c.trim();
+  API_END
+}
+
+void *bwt_hip_stream(bwt_hip_ctx *ctx) { return ctx ? (void *)ctx->c.stream : nullptr; }
+
+int bwt_hip_sync(bwt_hip_ctx *ctx) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  ctx->c.sync();
+  API_END
+}
+
+// ---------------------------------------------------------------------------
+// primitives for unit tests
+// ---------------------------------------------------------------------------
+template <class K>
+static void test_sort(Ctx &c, K *keys, u32 *vals, i64 n, int b0, int b1) {
+  if (n <= 0) return;
+  DBuf<K> k0(c, (size_t)n), k1(c, (size_t)n);
+  DBuf<u32> v0, v1;
+  HIP_CHECK(hipMemcpyAsync(k0.get(), keys, (size_t)n * sizeof(K), hipMemcpyHostToDevice, c.stream));
+  if (vals) {
+    v0 = DBuf<u32>(c, (size_t)n);
+    v1 = DBuf<u32>(c, (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(v0.get(), vals, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+  }
+  K *kk[2] = {k0.get(), k1.get()};
+  u32 *vv[2] = {v0.get(), v1.get()};
+  int cur;
+  if (sizeof(K) == 8)
+    cur = radix_sort_u64(c, (u64 **)kk, vv, (size_t)n, b0, b1);
+  else
+    cur = radix_sort_u32(c, (u32 **)kk, vv, (size_t)n, b0, b1);
+  HIP_CHECK(hipMemcpyAsync(keys, kk[cur], (size_t)n * sizeof(K), hipMemcpyDeviceToHost, c.stream));
+  if (vals) HIP_CHECK(hipMemcpyAsync(vals, vv[cur], (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+}
+
+int bwt_hip_test_sort_u64(bwt_hip_ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b0, int b1) {
+  API_BEGIN
+  need(ctx && keys, "ctx, keys");
+  need(b0 >= 0 && b0 <= b1 && b1 <= 64, "bit range");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  test_sort<u64>(ctx->c, keys, vals, n, b0, b1);
+  API_END
+}
+
+int bwt_hip_test_sort_u32(bwt_hip_ctx *ctx, uint32_t *keys, uint32_t *vals, int64_t n, int b0, int b1) {
+  API_BEGIN
+  need(ctx && keys, "ctx, keys");
+  need(b0 >= 0 && b0 <= b1 && b1 <= 32, "bit range");
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  test_sort<u32>(ctx->c, keys, vals, n, b0, b1);
+  API_END
+}
+
+int bwt_hip_test_scan_u32(bwt_hip_ctx *ctx, uint32_t *data, int64_t n, int op) {
+  API_BEGIN
+  need(ctx && data, "ctx, data");
+  need(op == 0 || op == 1, "op");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  if (n > 0) {
+    DBuf<u32> d(c, (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(d.get(), data, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+    if (op == 0)
+      scan_exclusive_u32(c, d.get(), d.get(), (size_t)n, nullptr);
+    else
+      scan_inclusive_max_u32(c, d.get(), d.get(), (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(data, d.get(), (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+  }
+  API_END
+}

@@ -1,0 +1,192 @@
+// Device context: caching allocator, phase timers, text utilities.
+#include <stdarg.h>
+
+#include "internal.h"
+#include "device_utils.h"
+
+namespace bwtamd {
+
+void fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+// ---------------------------------------------------------------------------
+// caching allocator.  hipMalloc/hipFree synchronise the device and cost
+// milliseconds at GB sizes, and one BWT build allocates dozens of GB-sized
+// temporaries; freed blocks are therefore kept and reused (best fit, up to
+// 25 % slack) until trim() or context destruction.
+// ---------------------------------------------------------------------------
+static size_t round_size(size_t b) {
+  if (b < 256) return 256;
+  if (b < (1u << 20)) return (b + 255) & ~(size_t)255;
+  return (b + ((1u << 21) - 1)) & ~(size_t)((1u << 21) - 1);
+}
+
+void *Ctx::alloc(size_t bytes) {
+  size_t sz = round_size(bytes);
+  auto it = free_blocks.lower_bound(sz);
+  void *p = nullptr;
+  if (it != free_blocks.end() && it->first <= sz + sz / 4 + (1u << 20)) {
+    p = it->second;
+    sz = it->first;
+    free_blocks.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(&p, sz);
+    }
+    if (e != hipSuccess)
+      fail((int)e, "hipMalloc of %zu bytes failed: %s", sz, hipGetErrorString(e));
+    bytes_reserved += sz;
+  }
+  live_blocks[p] = sz;
+  bytes_live += sz;
+  if (bytes_live > bytes_peak) bytes_peak = bytes_live;
+  return p;
+}
+
+void Ctx::release(void *p) {
+  if (!p) return;
+  auto it = live_blocks.find(p);
+  if (it == live_blocks.end()) return;
+  size_t sz = it->second;
+  live_blocks.erase(it);
+  bytes_live -= sz;
+  // Work queued on the stream may still read or write the block; any later
+  // user of the block is queued on the same stream, behind that work.
+  free_blocks.insert({sz, p});
+}
+
+void Ctx::trim() {
+  if (free_blocks.empty()) return;
+  (void)hipStreamSynchronize(stream);
+  for (auto &kv : free_blocks) {
+    (void)hipFree(kv.second);
+    bytes_reserved -= kv.first;
+  }
+  free_blocks.clear();
+}
+
+void Ctx::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+// ---------------------------------------------------------------------------
+// phase timers
+// ---------------------------------------------------------------------------
+int Ctx::timer_index(const char *name) {
+  for (size_t i = 0; i < timers.size(); i++)
+    if (timers[i].name == name) return (int)i;
+  PhaseTimer t;
+  t.name = name;
+  timers.push_back(t);
+  return (int)timers.size() - 1;
+}
+
+static hipEvent_t get_event(Ctx &c) {
+  if (!c.event_pool.empty()) {
+    hipEvent_t e = c.event_pool.back();
+    c.event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+
+Phase::Phase(Ctx &ctx, const char *name, double bytes) : c(ctx) {
+  if (c.timing_level <= 0) return;
+  idx = c.timer_index(name);
+  c.timers[idx].bytes += bytes;
+  c.timers[idx].launches++;
+  e0 = get_event(c);
+  (void)hipEventRecord(e0, c.stream);
+}
+
+Phase::~Phase() {
+  if (idx < 0) return;
+  hipEvent_t e1 = nullptr;
+  try {
+    e1 = get_event(c);
+  } catch (...) {
+    return;
+  }
+  (void)hipEventRecord(e1, c.stream);
+  c.pending.push_back({idx, e0, e1});
+}
+
+void Ctx::flush_timers() {
+  if (pending.empty()) return;
+  sync();
+  for (auto &p : pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) timers[p.idx].ms += ms;
+    event_pool.push_back(p.e0);
+    event_pool.push_back(p.e1);
+  }
+  pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+// text utilities
+// ---------------------------------------------------------------------------
+
+// T[i] = 1 + splitmix64(seed, i) % sigma for i < n-1, T[n-1] = 0: the same
+// stream as the CPU generators of the tests, one element per counter value.
+__global__ void k_gen_text(u8 *T, u64 n, u64 seed, u32 sigma) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    T[i] = (i + 1 == n) ? (u8)0 : (u8)(1 + z % sigma);
+  }
+}
+
+void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma) {
+  u32 blocks = (u32)std::min<u64>(ceil_div(n, 256), (u64)c.n_cu * 32);
+  hipLaunchKernelGGL(k_gen_text, dim3(blocks), dim3(256), 0, c.stream, dT, (u64)n, seed, (u32)sigma);
+  HIP_CHECK(hipGetLastError());
+}
+
+// out[0] = max symbol, out[1] = number of zeros (saturating at 2^31)
+__global__ void k_text_stats(const u8 *T, u64 n, u32 *out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 stride = (u64)gridDim.x * blockDim.x;
+  u32 mx = 0, nz = 0;
+  for (; i < n; i += stride) {
+    u32 v = T[i];
+    mx = max(mx, v);
+    nz += (v == 0);
+  }
+  mx = wave_reduce_max(mx);
+  nz = wave_reduce_sum(nz);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], mx);
+    atomicAdd(&out[1], nz);
+  }
+}
+
+void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, i64 *n_zero, int *last) {
+  HIP_CHECK(hipMemsetAsync(c.d_scalars, 0, 8, c.stream));
+  u32 blocks = (u32)std::min<u64>(ceil_div(n, 256 * 16), (u64)c.n_cu * 16);
+  hipLaunchKernelGGL(k_text_stats, dim3(blocks), dim3(256), 0, c.stream, dT, (u64)n, c.d_scalars);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.d_scalars, 8, hipMemcpyDeviceToHost, c.stream));
+  u8 lastc = 0;
+  HIP_CHECK(hipMemcpyAsync(&c.h_scalars[2], dT + n - 1, 1, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  lastc = *(u8 *)&c.h_scalars[2];
+  *max_sym = (int)c.h_scalars[0];
+  *n_zero = (i64)c.h_scalars[1];
+  *last = lastc;
+}
+
+}  // namespace bwtamd

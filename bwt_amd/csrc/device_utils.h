@@ -1,0 +1,98 @@
+// Device-side helpers shared by the kernels: 64-lane wave scans/reductions and
+// block-wide combinations of them.  gfx950 only: a wave is 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bwtamd {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+#define WAVE 64
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ u32 wave_reduce_sum(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_reduce_max(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor(v, o, 64));
+  return v;
+}
+
+// inclusive scans across the 64 lanes of a wave
+__device__ __forceinline__ u32 wave_scan_incl_sum(u32 v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 t = __shfl_up(v, o, 64);
+    if (lane_id() >= (u32)o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_scan_incl_max(u32 v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 t = __shfl_up(v, o, 64);
+    if (lane_id() >= (u32)o) v = max(v, t);
+  }
+  return v;
+}
+
+struct OpSum {
+  __device__ __forceinline__ static u32 identity() { return 0; }
+  __device__ __forceinline__ static u32 apply(u32 a, u32 b) { return a + b; }
+  __device__ __forceinline__ static u32 wave_incl(u32 v) { return wave_scan_incl_sum(v); }
+};
+struct OpMax {
+  __device__ __forceinline__ static u32 identity() { return 0; }
+  __device__ __forceinline__ static u32 apply(u32 a, u32 b) { return max(a, b); }
+  __device__ __forceinline__ static u32 wave_incl(u32 v) { return wave_scan_incl_max(v); }
+};
+
+// Block-wide inclusive scan of one value per thread (blockDim.x <= 1024, a
+// multiple of 64).  `smem` must hold 17 words.  Returns the inclusive value;
+// *block_total receives the combination of all threads' values.  Contains
+// two __syncthreads(); every thread of the block must call it.
+template <class Op>
+__device__ __forceinline__ u32 block_scan_incl(u32 v, u32 *smem, u32 *block_total) {
+  u32 incl = Op::wave_incl(v);
+  u32 w = wave_id(), nw = blockDim.x >> 6;
+  __syncthreads();  // smem may still be read from a previous call
+  if (lane_id() == 63) smem[w] = incl;
+  __syncthreads();
+  u32 carry = Op::identity(), tot = Op::identity();
+  for (u32 k = 0; k < nw; k++) {
+    u32 s = smem[k];
+    if (k < w) carry = Op::apply(carry, s);
+    tot = Op::apply(tot, s);
+  }
+  *block_total = tot;
+  return Op::apply(carry, incl);
+}
+
+// Which lanes of the wave hold the same 8-bit digit as this lane, among the
+// lanes flagged valid.  Eight ballots: one per digit bit.
+__device__ __forceinline__ u64 match_digit8(u32 digit, bool valid) {
+  u64 m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    bool bit = (digit >> b) & 1;
+    u64 bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+}  // namespace bwtamd

@@ -1,0 +1,206 @@
+// Internal C++ interface between the translation units of libbwt_hip.so.
+// Nothing here is part of the C-ABI (see include/bwt_hip.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace bwtamd {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// ---------------------------------------------------------------------------
+// errors: internal code throws, the C-ABI layer converts to a status + message
+// ---------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int code_, const std::string &what) : std::runtime_error(what), code(code_) {}
+};
+
+[[noreturn]] void fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_CHECK(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      ::bwtamd::fail((int)e__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                     __LINE__);                                                                \
+  } while (0)
+
+// status codes of the C-ABI that are not hipError_t values (same values as include/bwt_hip.h)
+#ifndef BWT_HIP_EINVAL
+#define BWT_HIP_EINVAL 10001
+#define BWT_HIP_ETEXT 10002
+#define BWT_HIP_EINTERNAL 10003
+#endif
+
+// ---------------------------------------------------------------------------
+// device context: one per (process, GPU).  All work runs on `stream`.
+// ---------------------------------------------------------------------------
+struct PhaseTimer {
+  std::string name;
+  double ms = 0;
+  double bytes = 0;  // algorithmic bytes (or transactions) of the phase
+  long launches = 0;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 256;
+
+  // text
+  const u8 *T = nullptr;  // device
+  u8 *T_owned = nullptr;
+  i64 n = 0;
+  int max_sym = 0;  // largest symbol in T
+  int sym_bits = 0; // bits per symbol = floor(log2(max_sym)) + 1
+
+  // caching allocator (sizes rounded up; freed blocks are kept for reuse)
+  std::multimap<size_t, void *> free_blocks;
+  std::unordered_map<void *, size_t> live_blocks;
+  size_t bytes_live = 0, bytes_peak = 0, bytes_reserved = 0;
+
+  // phase timing (hipEvent pairs on `stream`), enabled by timing_level > 0
+  int timing_level = 0;
+  std::vector<PhaseTimer> timers;
+  struct Pending {
+    int idx;
+    hipEvent_t e0, e1;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  // small pinned host scratch for scalar read-backs
+  u32 *h_scalars = nullptr;  // 64 words, pinned
+  u32 *d_scalars = nullptr;  // 64 words, device
+
+  void *alloc(size_t bytes);
+  void release(void *p);
+  void trim();  // return cached blocks to the driver
+  void sync();
+
+  int timer_index(const char *name);
+  void flush_timers();
+};
+
+// RAII handle on pool memory
+template <class T>
+struct DBuf {
+  Ctx *c = nullptr;
+  T *p = nullptr;
+  size_t n = 0;
+  DBuf() {}
+  DBuf(Ctx &ctx, size_t count) : c(&ctx), n(count) { p = (T *)ctx.alloc(count * sizeof(T)); }
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  DBuf(DBuf &&o) : c(o.c), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf &operator=(DBuf &&o) {
+    if (this != &o) {
+      reset();
+      c = o.c;
+      p = o.p;
+      n = o.n;
+      o.p = nullptr;
+    }
+    return *this;
+  }
+  ~DBuf() { reset(); }
+  void reset() {
+    if (p) c->release(p);
+    p = nullptr;
+  }
+  T *get() const { return p; }
+  operator T *() const { return p; }
+};
+
+// scoped phase timer: records two events on the stream when timing is on
+struct Phase {
+  Ctx &c;
+  int idx = -1;
+  hipEvent_t e0 = nullptr;
+  Phase(Ctx &ctx, const char *name, double bytes = 0);
+  ~Phase();
+};
+
+static inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// primitives (scan.hip, radix_sort.hip)
+// ---------------------------------------------------------------------------
+
+// out[i] = sum_{k<i} in[k]  (u32, wraps); in and out may alias.  If total is
+// not null, *total (device) receives the sum of all entries.
+void scan_exclusive_u32(Ctx &c, const u32 *in, u32 *out, size_t n, u32 *total);
+// out[i] = max_{k<=i} in[k]; in and out may alias.
+void scan_inclusive_max_u32(Ctx &c, const u32 *in, u32 *out, size_t n);
+
+// Stable LSD radix sort of n (key, val) pairs on key bits [begin_bit,end_bit).
+// keys[0]/vals[0] hold the input; the other pair is scratch of the same size.
+// vals may be {nullptr,nullptr} for keys only.  Returns which pair (0 or 1)
+// holds the result.  n < 2^32.
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
+int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
+
+// ---------------------------------------------------------------------------
+// a partial BWT resident on the device (include/bwt.h:122-149 of the reference)
+// ---------------------------------------------------------------------------
+struct WaveletDev {
+  int levels = 0;
+  u64 n_blk = 0;        // 64-byte rank blocks per level
+  DBuf<u64> planes;     // levels * n_blk * 8 words
+  u32 n_zeros[8] = {0}; // zeros per level
+  DBuf<u32> lf_base;    // 256 entries: C[c] - p_end[c]
+  bool built = false;
+};
+
+struct Block {
+  i64 a = 0, b = 0;
+  u8 e_char = 0;
+  i64 s_rank = -1, e_rank = -1;  // relative to a
+  DBuf<u8> L;                    // b-a symbols
+  DBuf<u32> samp_rank;           // relative to a, ordered by pos
+  DBuf<u32> samp_pos;            // absolute text positions, ascending
+  i64 n_samp = 0;
+  i64 hist[256];                 // symbol counts of L (filled by count_alphabets)
+  i64 C[257];                    // C[c] = #symbols < c in T[a:b)
+  bool counted = false;
+  WaveletDev wm;
+  i64 len() const { return b - a; }
+};
+
+// suffix_sort.hip: SA of T[a:b) in full-text suffix order, absolute positions
+DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b);
+// leaf.hip
+Block *leaf_from_sa(Ctx &c, i64 a, i64 b, const u32 *sa, i64 ns);
+// wavelet.hip
+void count_alphabets(Ctx &c, Block &blk);
+void build_wavelet(Ctx &c, Block &blk);
+void rank_batch(Ctx &c, Block &blk, const u8 *d_sym, const u32 *d_pos, u32 *d_out, size_t nq, bool lf);
+// gap.hip: the inclusive prefix sums S[i] = #{j : g_j <= i}, i in [0, m], of
+// the gap array, plus g_j at the right block's sample positions
+struct GapResult {
+  DBuf<u32> S;       // m + 1 entries
+  DBuf<u32> samp_g;  // one per sample of the right block
+  DBuf<u32> g_text;  // optional tap: g_j for j = r.a .. r.b-1
+  i64 seg = 0, n_chains = 0;
+};
+GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg, bool want_g);
+// merge.hip
+Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
+
+void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
+void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, i64 *n_zero, int *last);
+
+}  // namespace bwtamd

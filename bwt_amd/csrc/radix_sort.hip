@@ -1,0 +1,161 @@
+// Stable LSD radix sort, 8 bits per pass, for (u64|u32 key, optional u32 value).
+//
+// One pass = three launches:
+//   k_rs_hist     per-tile digit counts          reads keys
+//   scan          exclusive scan of [digit][tile] counts
+//   k_rs_scatter  ranks the tile's keys per digit, orders the tile in LDS and
+//                 writes each digit's run to its global offset
+//                                                reads keys+vals, writes keys+vals
+// Algorithmic HBM bytes per element and pass: 2*sizeof(K) + sizeof(K) + 2*4 (with values).
+//
+// Ranking inside a tile is atomic-free: a wave owns 1024 consecutive keys and
+// walks them 64 at a time; eight ballots find the lanes that share a digit, the
+// lowest of them bumps the wave's private LDS counter, so equal digits keep
+// their input order (the sort is stable, which LSD needs).
+#include "device_utils.h"
+#include "internal.h"
+
+namespace bwtamd {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES; // 1024 consecutive keys per wave
+
+template <class K>
+__global__ void __launch_bounds__(RS_THREADS)
+    k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk) {
+  __shared__ u32 cnt[RS_WAVES][256];
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
+  const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+  volatile u32 *myc = cnt[w];
+#pragma unroll 4
+  for (int r = 0; r < RS_ITEMS; r++) {
+    size_t i = tile0 + (size_t)r * RS_THREADS + tid;
+    bool valid = i < n;
+    K k = valid ? keys[i] : (K)0;
+    u32 d = (u32)(k >> shift) & mask;
+    u64 peers = match_digit8(d, valid);
+    if (valid && (peers & lanemask_lt()) == 0) myc[d] = myc[d] + __popcll(peers);
+  }
+  __syncthreads();
+  u32 tot = 0;
+#pragma unroll
+  for (int k = 0; k < RS_WAVES; k++) tot += cnt[k][tid];
+  counts[(size_t)tid * nblk + blockIdx.x] = tot;
+}
+
+template <class K, bool HAS_VALS>
+__global__ void __launch_bounds__(RS_THREADS)
+    k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
+                 u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
+                 u32 nblk) {
+  __shared__ K keys_s[RS_TILE];
+  __shared__ u32 vals_s[HAS_VALS ? RS_TILE : 1];
+  __shared__ u32 cnt[RS_WAVES][256];
+  __shared__ u32 dstart[256];
+  __shared__ u32 gbase[256];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+  const u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
+  for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
+
+  K key[RS_ITEMS];
+  u32 val[RS_ITEMS];
+  u32 rk[RS_ITEMS];
+  const u32 wbase = w * RS_PER_WAVE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    u32 idx = wbase + r * 64 + lane;
+    bool valid = idx < tile_n;
+    key[r] = valid ? kin[tile0 + idx] : (K)0;
+    if (HAS_VALS) val[r] = valid ? vin[tile0 + idx] : 0u;
+  }
+  volatile u32 *myc = cnt[w];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    u32 idx = wbase + r * 64 + lane;
+    bool valid = idx < tile_n;
+    u32 d = (u32)(key[r] >> shift) & mask;
+    u64 peers = match_digit8(d, valid);
+    u32 before = __popcll(peers & lanemask_lt());
+    u32 base = valid ? myc[d] : 0u;
+    rk[r] = base + before;
+    if (valid && before == 0) myc[d] = base + __popcll(peers);
+  }
+  __syncthreads();
+  {
+    // thread tid owns digit tid: wave counts -> wave offsets, digit totals -> tile-local digit starts
+    u32 c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+    u32 tot = c0 + c1 + c2 + c3;
+    cnt[0][tid] = 0;
+    cnt[1][tid] = c0;
+    cnt[2][tid] = c0 + c1;
+    cnt[3][tid] = c0 + c1 + c2;
+    u32 all;
+    u32 incl = block_scan_incl<OpSum>(tot, scan_s, &all);
+    u32 ds = incl - tot;
+    dstart[tid] = ds;
+    gbase[tid] = offs[(size_t)tid * nblk + blockIdx.x] - ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    u32 idx = wbase + r * 64 + lane;
+    if (idx < tile_n) {
+      u32 d = (u32)(key[r] >> shift) & mask;
+      u32 pos = dstart[d] + cnt[w][d] + rk[r];
+      keys_s[pos] = key[r];
+      if (HAS_VALS) vals_s[pos] = val[r];
+    }
+  }
+  __syncthreads();
+  for (u32 p = tid; p < tile_n; p += RS_THREADS) {
+    K k = keys_s[p];
+    u32 d = (u32)(k >> shift) & mask;
+    u32 dst = gbase[d] + p;
+    kout[dst] = k;
+    if (HAS_VALS) vout[dst] = vals_s[p];
+  }
+}
+
+template <class K>
+static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
+  if (n == 0 || end_bit <= begin_bit) return 0;
+  if (n >= (1ull << 32)) fail(BWT_HIP_EINVAL, "radix sort: %zu elements exceed 2^32-1", n);
+  u32 nblk = ceil_div(n, RS_TILE);
+  DBuf<u32> counts(c, (size_t)256 * nblk);
+  const bool has_vals = vals[0] != nullptr;
+  int cur = 0;
+  for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    u32 mask = (1u << bits) - 1;
+    hipLaunchKernelGGL((k_rs_hist<K>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur], n, shift, mask,
+                       counts.get(), nblk);
+    HIP_CHECK(hipGetLastError());
+    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+    if (has_vals)
+      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+                         vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk);
+    else
+      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+                         (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(),
+                         nblk);
+    HIP_CHECK(hipGetLastError());
+    cur ^= 1;
+  }
+  return cur;
+}
+
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
+  return radix_sort_impl<u64>(c, keys, vals, n, begin_bit, end_bit);
+}
+
+int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
+  return radix_sort_impl<u32>(c, keys, vals, n, begin_bit, end_bit);
+}
+
+}  // namespace bwtamd

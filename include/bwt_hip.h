@@ -1,0 +1,178 @@
+/*
+ * bwt_hip.h -- C-ABI of libbwt_hip.so, the MI355X (gfx950) implementation of
+ * taura/bwt's build-leaf-then-merge BWT path.
+ *
+ * The reference has no FFI; its boundary is the header API of include/bwt.h
+ * (bwt::pmbwt, bwt_rec, bwt_leaf, bwt_merge, struct bwt).  The drop-in C++
+ * headers shipped next to this file (bwt.h, opts.h, util.h, ...) keep that API
+ * and implement it with the entry points below.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference's root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; int64_t indices (the reference's idx_t).
+ *   - return value: 0 on success, otherwise a hipError_t value or one of
+ *     BWT_HIP_E*; bwt_hip_last_error() returns the message of the calling
+ *     thread's last failure.  Nothing aborts and nothing throws across the ABI.
+ *   - one context per (process, GPU); a context and its blocks are used by one
+ *     host thread at a time, like the reference (its global `stat`, util.h:209).
+ *   - the text obeys the reference's contract (README.md:66-68): T[n-1] == 0
+ *     and no other 0.  n <= 2^32 - 4.
+ *   - ranks taken or returned are absolute (rank r of block [a,b) lies in
+ *     [a,b)), as in the reference.
+ */
+#ifndef BWT_HIP_H
+#define BWT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bwt_hip_ctx bwt_hip_ctx;     /* device context */
+typedef struct bwt_hip_block bwt_hip_block; /* partial BWT of T[a:b) resident in HBM (struct bwt, include/bwt.h:122-149) */
+
+#define BWT_HIP_EINVAL 10001    /* bad argument */
+#define BWT_HIP_ETEXT 10002     /* text breaks the contract above */
+#define BWT_HIP_EINTERNAL 10003 /* internal invariant failed */
+
+const char *bwt_hip_last_error(void);
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`.  Replaces nothing in the
+   reference (which has no device); lifetime brackets what `mallocator mem`
+   brackets in src/pmbwt.cc:317-332. */
+int bwt_hip_create(int device, bwt_hip_ctx **out);
+void bwt_hip_destroy(bwt_hip_ctx *ctx);
+
+/* Copies the host text T[0:n) to the device and validates it.
+   Replaces the `const alpha_t * T, idx_t n` arguments of bwt::pmbwt
+   (include/bwt.h:867). */
+int bwt_hip_set_text(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n);
+
+/* Uses a text already in device memory (borrowed, 16-byte aligned, must stay
+   valid while the context uses it).  Same role as bwt_hip_set_text. */
+int bwt_hip_set_text_device(bwt_hip_ctx *ctx, const uint8_t *T_dev, int64_t n);
+
+/* Fills a device text with the synthetic stream of the benchmarks:
+   x_i = splitmix64(seed + (i+1)*0x9E3779B97F4A7C15), T[i] = 1 + x_i % sigma,
+   T[n-1] = 0.  Replaces gen_input of src/pmbwt.cc:34-48 (whose nrand48() % 4
+   text is periodic and unusable for 4-letter alphabets). */
+int bwt_hip_gen_text(bwt_hip_ctx *ctx, int64_t n, uint64_t seed, int sigma);
+
+/* Copies the context's text back to the host (n bytes). */
+int bwt_hip_get_text(bwt_hip_ctx *ctx, uint8_t *T_host);
+
+/* ---- the pipeline ------------------------------------------------------ */
+
+/* bwt::bwt_leaf (include/bwt.h:615-635): BWT of T[a:b) from its suffix array
+   in full-text suffix order, plus min(b-a, ssa_n_samples) samples. */
+int bwt_hip_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ssa_n_samples, bwt_hip_block **out);
+
+/* bwt::bwt_merge (include/bwt.h:791-847): merges adjacent blocks l=[a,c) and
+   r=[c,b) into [a,b).  Consumes (frees) l and r.  build_gap_segment_sz is
+   bwt_opt's field of that name (include/opts.h:112); 0 = 1024. */
+int bwt_hip_merge(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t ssa_n_samples,
+                  int64_t build_gap_segment_sz, bwt_hip_block **out);
+
+/* bwt::bwt_rec (include/bwt.h:854-865) over [a,b): leaf iff
+   b-a <= bwt_rec_threshold, else split at (a+b)/2 and merge. */
+int bwt_hip_rec(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
+                int64_t build_gap_segment_sz, bwt_hip_block **out);
+
+/* bwt::pmbwt (include/bwt.h:867-883): bwt_hip_rec over [0,n). */
+int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
+                  int64_t build_gap_segment_sz, bwt_hip_block **out);
+
+/* Uploads a block computed elsewhere (host L[a:b) as the reference stores it in
+   L + a, samples ordered by pos).  Lets bwt::bwt_merge run on blocks whose
+   device copy was dropped.  Counterpart of passing `bwt& l` by reference
+   (include/bwt.h:791). */
+int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *L_host, int64_t s_rank,
+                         int64_t e_rank, const int64_t *samp_rank, const int64_t *samp_pos, int64_t n_samples,
+                         bwt_hip_block **out);
+
+/* bwt::fini (include/bwt.h:174-182) */
+void bwt_hip_block_free(bwt_hip_ctx *ctx, bwt_hip_block *blk);
+
+/* ---- reading a block ---------------------------------------------------- */
+
+/* The scalar fields of struct bwt (include/bwt.h:135-145); any out pointer may be null. */
+int bwt_hip_block_info(const bwt_hip_block *blk, int64_t *a, int64_t *b, int64_t *s_rank, int64_t *e_rank,
+                       int *e_char, int64_t *n_samples);
+
+/* Copies L[a:b) (b-a bytes) to the host: what the reference leaves in L + a. */
+int bwt_hip_block_get_L(bwt_hip_ctx *ctx, const bwt_hip_block *blk, uint8_t *L_host);
+
+/* Device address of L[a:b) (valid until the block is freed or merged). */
+int bwt_hip_block_L_device(const bwt_hip_block *blk, const uint8_t **L_dev);
+
+/* The sampled suffix array (include/sampled_suffix_array.h:36-39 entries),
+   ordered by pos; writes min(n_samples, cap) pairs. */
+int bwt_hip_block_get_samples(bwt_hip_ctx *ctx, const bwt_hip_block *blk, int64_t *rank_out, int64_t *pos_out,
+                              int64_t cap);
+
+/* ---- per-phase taps (parity tests, host-side helpers) -------------------- */
+
+/* sa_range (include/suffix_array.h:34-49): SA_host[r] = position of rank a+r. */
+int bwt_hip_leaf_sa(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t *SA_host);
+
+/* bwt::init_extra (include/bwt.h:169-172): count_alphabets + wavelet matrix. */
+int bwt_hip_block_init_extra(bwt_hip_ctx *ctx, bwt_hip_block *blk);
+
+/* C[0..alpha_max] of include/bwt.h:200-226 (alpha_max + 1 entries, alpha_max <= 255). */
+int bwt_hip_block_get_C(bwt_hip_ctx *ctx, bwt_hip_block *blk, int alpha_max, int64_t *C_out);
+
+/* Batched wavelet_matrix::rank (include/wavelet_matrix.h:260-290):
+   out[k] = occurrences of sym[k] in the block's L[0:pos[k]) with T[a-1] hidden;
+   pos relative to a. */
+int bwt_hip_block_rank(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uint8_t *sym, const int64_t *pos,
+                       int64_t *out);
+
+/* Batched bwt::LF_map_mod (include/bwt.h:253-259): absolute ranks in and out. */
+int bwt_hip_block_LF(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uint8_t *sym, const int64_t *rank,
+                     int64_t *out);
+
+/* build_gap (include/bwt.h:730-787) without consuming the blocks:
+   gap_out[i - l.a] = gap.get(i) for i in [l.a, l.b] (l.b-l.a+1 entries);
+   g_out[j - r.a] = insertion point of T[j:] among l's suffixes, absolute
+   (r.b-r.a entries).  Either may be null. */
+int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t build_gap_segment_sz,
+                int64_t *gap_out, int64_t *g_out);
+
+/* ---- observability ------------------------------------------------------- */
+
+/* level > 0 records a hipEvent pair around every phase on the context's stream. */
+int bwt_hip_set_timing(bwt_hip_ctx *ctx, int level);
+int bwt_hip_reset_timers(bwt_hip_ctx *ctx);
+/* Number of named phases; then per phase its name, accumulated milliseconds,
+   algorithmic bytes (transactions for gap_chains) and launch count.  Stands in
+   for ts_stat (include/util.h:138-209). */
+int bwt_hip_timer_count(bwt_hip_ctx *ctx);
+int bwt_hip_timer_get(bwt_hip_ctx *ctx, int idx, const char **name, double *ms, double *work, int64_t *calls);
+
+/* Device memory accounting, the counterpart of mallocator's counters
+   (include/util.h:267-276): bytes live now, high-water mark, bytes held from the driver. */
+int bwt_hip_mem_stats(bwt_hip_ctx *ctx, int64_t *live, int64_t *peak, int64_t *reserved);
+/* Returns cached device memory to the driver. */
+int bwt_hip_trim(bwt_hip_ctx *ctx);
+
+/* The HIP stream all of the context's work is queued on (a hipStream_t). */
+void *bwt_hip_stream(bwt_hip_ctx *ctx);
+/* Waits for all queued work. */
+int bwt_hip_sync(bwt_hip_ctx *ctx);
+
+/* ---- primitives exposed for unit tests ----------------------------------- */
+
+/* Stable LSD radix sort of host arrays on the device, key bits [begin_bit,end_bit);
+   vals may be null. */
+int bwt_hip_test_sort_u64(bwt_hip_ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit, int end_bit);
+int bwt_hip_test_sort_u32(bwt_hip_ctx *ctx, uint32_t *keys, uint32_t *vals, int64_t n, int begin_bit, int end_bit);
+/* op 0: exclusive sum, op 1: inclusive max; in place on a host array. */
+int bwt_hip_test_scan_u32(bwt_hip_ctx *ctx, uint32_t *data, int64_t n, int op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BWT_HIP_H */

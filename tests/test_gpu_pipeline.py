@@ -1,0 +1,109 @@
+"""GPU parity of the whole path bwt::pmbwt (include/bwt.h:867-883) through the C-ABI: golden vectors of the real
+reference, the oracle on seeded inputs, and size-independent properties at sizes the CPU cannot check."""
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from tests.golden_util import check_block, h8, load_golden, make_text
+from tests.gpu_util import ctx, inverse_bwt  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+G = load_golden()
+
+
+@pytest.mark.parametrize("rec", G["pipeline"], ids=lambda r: r["name"])
+def test_pipeline_golden(ctx, rec):
+    T = make_text(rec["text"])
+    ctx.set_text(T)
+    blk = ctx.pmbwt(rec["bwt_rec_threshold"], rec["ssa_n_samples"], rec["opts"].get("seg", 0))
+    check_block(blk, blk.L, rec, 0, len(T))
+
+
+def test_mississippi(ctx):
+    # src/simplest_example.cc: BWT("mississippi\0") = ipssm\0pissii
+    ctx.set_text(np.frombuffer(b"mississippi\0", dtype=np.uint8))
+    for th in (12, 6, 3, 1):
+        blk = ctx.pmbwt(th, 4)
+        assert bytes(blk.L) == b"ipssm\0pissii"
+        assert (blk.s_rank, blk.e_rank) == (5, 0)
+
+
+@pytest.mark.parametrize("sigma,n,th,ns,seg", [(4, 200000, 200000, 1000, 0), (4, 200000, 30000, 1000, 0),
+                                               (4, 200000, 1500, 300, 50), (255, 150000, 40000, 2000, 0),
+                                               (26, 99991, 7000, 500, 333), (3, 5000, 100, 20, 16)])
+def test_pipeline_against_oracle(ctx, sigma, n, th, ns, seg):
+    """src/test/test_rec.cc re-expressed (recursion + round trip), plus exact equality with the oracle."""
+    T = make_text({"kind": "splitmix", "n": n, "seed": 1000 + sigma, "sigma": sigma})
+    ctx.set_text(T)
+    blk = ctx.pmbwt(th, ns, seg)
+    L = blk.L
+    o = Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (L == ob.L).all()
+    assert (blk.s_rank, blk.e_rank, blk.e_char) == (ob.s_rank, ob.e_rank, ob.e_char)
+    for x, y in zip(blk.samples(), ob.samples()):
+        assert (x == y).all()
+    if n <= 200000:
+        assert (inverse_bwt(L, blk.e_rank) == T).all()  # src/pmbwt.cc:64-81
+
+
+def test_subrange_recursion(ctx):
+    """bwt_rec on a proper sub-range [a,b) of the text, as src/test/test_rec.cc does with random ranges."""
+    T = make_text({"kind": "splitmix", "n": 60000, "seed": 31, "sigma": 4})
+    ctx.set_text(T)
+    a, b = 1234, 54321
+    blk = ctx.rec(a, b, 5000, 200, 128)
+    o = Oracle.opt(len(T), alpha_min=1, alpha_max=4, bwt_rec_threshold=5000, ssa_n_samples=200, build_gap_segment_sz=128)
+    Lo = np.zeros(len(T), dtype=np.uint8)
+
+    def rec(lo, hi):
+        if hi - lo <= 5000:
+            return Oracle.leaf(T, lo, hi, Lo, o)
+        mid = (lo + hi) // 2
+        return Oracle.merge(rec(lo, mid), rec(mid, hi), o)
+    ob = rec(a, b)
+    assert (blk.L == Lo[a:b]).all()
+    assert (blk.s_rank, blk.e_rank) == (ob.s_rank, ob.e_rank)
+    for x, y in zip(blk.samples(), ob.samples()):
+        assert (x == y).all()
+
+
+def _properties(ctx, n, sigma, seed, thresholds, ns):
+    """Size-independent checks: L is a permutation of T, does not depend on the leaf size, and every sample
+    (rank, pos) satisfies L[rank] = T[pos-1]."""
+    ctx.gen_text(n, seed, sigma)
+    T = ctx.get_text()
+    ref = None
+    for th in thresholds:
+        blk = ctx.pmbwt(th, ns)
+        L = blk.L
+        assert (np.bincount(L, minlength=256) == np.bincount(T, minlength=256)).all()
+        assert L[blk.s_rank] == 0 and blk.e_rank == 0
+        r, p = blk.samples()
+        assert p[0] == 0 and p[-1] == n - 1 and (np.diff(p) > 0).all()
+        assert (L[r] == T[p - 1]).all()
+        if ref is None:
+            ref = L
+        else:
+            assert (L == ref).all()
+        blk.free()
+    return T, ref
+
+
+def test_properties_dna_16m(ctx):
+    n = 1 << 24
+    T, L = _properties(ctx, n, 4, 42, [n, n // 2, n // 5], 100000)
+    assert (T == make_text({"kind": "splitmix", "n": n, "seed": 42, "sigma": 4})).all()
+
+
+def test_properties_bytes_8m(ctx):
+    n = 1 << 23
+    _properties(ctx, n, 255, 42, [n, n // 3], 50000)
+
+
+def test_golden_1e6_from_device_generator(ctx):
+    """The device text generator and the CPU one are the same stream: same golden hash as the reference."""
+    rec = [r for r in G["pipeline"] if r["name"] == "splitmix_s4_n1000000"][0]
+    ctx.gen_text(1000000, 42, 4)
+    blk = ctx.pmbwt(rec["bwt_rec_threshold"], rec["ssa_n_samples"])
+    assert h8(blk.L) == rec["L_fnv"] and blk.s_rank == rec["s_rank"]
