@@ -211,7 +211,9 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
     Phase ph(c, "gap_histogram", (double)total * ((bits + 7) / 8) * 12 + (double)(m + 1) * 12);
     u32 *keys[2] = {g0.get(), g1.get()};
     u32 *vals[2] = {nullptr, nullptr};
+    c.sort_tag = "gap:";
     int cur = radix_sort_u32(c, keys, vals, total, 0, bits);
+    c.sort_tag = "";
     G.S = DBuf<u32>(c, m + 1);
     HIP_CHECK(hipMemsetAsync(G.S.get(), 0, (m + 1) * 4, c.stream));
     hipLaunchKernelGGL(k_run_ends, dim3(ceil_div(rn, 256)), dim3(256), 0, c.stream, keys[cur], (u32)rn, G.S.get());

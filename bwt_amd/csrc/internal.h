@@ -74,6 +74,7 @@ struct Ctx {
 
   // phase timing (hipEvent pairs on `stream`), enabled by timing_level > 0
   int timing_level = 0;
+  const char *sort_tag = "";  // prefix of the radix sort's per-kernel timer names (who is sorting)
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;
@@ -132,6 +133,15 @@ struct Phase {
   hipEvent_t e0 = nullptr;
   Phase(Ctx &ctx, const char *name, double bytes = 0);
   ~Phase();
+};
+
+// the same around ONE kernel launch, recorded only at timing_level >= 2
+struct KernelTimer {
+  Phase *ph = nullptr;
+  KernelTimer(Ctx &ctx, const char *name, double bytes) {
+    if (ctx.timing_level >= 2) ph = new Phase(ctx, name, bytes);
+  }
+  ~KernelTimer() { delete ph; }
 };
 
 static inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }

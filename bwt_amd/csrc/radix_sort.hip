@@ -133,18 +133,27 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     u32 mask = (1u << bits) - 1;
-    hipLaunchKernelGGL((k_rs_hist<K>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur], n, shift, mask,
-                       counts.get(), nblk);
-    HIP_CHECK(hipGetLastError());
+    {
+      KernelTimer kt(c, (std::string(c.sort_tag) + (sizeof(K) == 8 ? "k_rs_hist_u64" : "k_rs_hist_u32")).c_str(),
+                     (double)n * sizeof(K));
+      hipLaunchKernelGGL((k_rs_hist<K>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur], n, shift, mask,
+                         counts.get(), nblk);
+      HIP_CHECK(hipGetLastError());
+    }
     scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
-    if (has_vals)
-      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
-                         vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk);
-    else
-      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
-                         (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(),
-                         nblk);
-    HIP_CHECK(hipGetLastError());
+    {
+      const char *nm = sizeof(K) == 8 ? (has_vals ? "k_rs_scatter_u64_pairs" : "k_rs_scatter_u64_keys")
+                                      : (has_vals ? "k_rs_scatter_u32_pairs" : "k_rs_scatter_u32_keys");
+      KernelTimer kt(c, (std::string(c.sort_tag) + nm).c_str(), (double)n * 2 * (sizeof(K) + (has_vals ? 4 : 0)));
+      if (has_vals)
+        hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+                           vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk);
+      else
+        hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+                           (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(),
+                           nblk);
+      HIP_CHECK(hipGetLastError());
+    }
     cur ^= 1;
   }
   return cur;

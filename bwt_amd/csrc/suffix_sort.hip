@@ -227,7 +227,9 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
   {
     int passes = (64 - low_bit + 7) / 8;
     Phase ph(c, "leaf_radix_sort", (double)N * passes * 32);
+    c.sort_tag = "leaf:";
     cur = radix_sort_u64(c, keys, vals, N, low_bit, 64);
+    c.sort_tag = "";
   }
   u32 *sa = vals[cur];
   u32 *d_total = c.d_scalars + 8;
@@ -271,7 +273,9 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
     HIP_CHECK(hipGetLastError());
     u64 *ck[2] = {ck0.get(), ck1.get()};
     u32 *cp[2] = {cp0.get(), cp1.get()};
+    c.sort_tag = "refine:";
     int cc = radix_sort_u64(c, ck, cp, M, 0, 32 + gbits);
+    c.sort_tag = "";
     DBuf<u32> ns(c, M), np(c, M), ng(c, M);
     scan_generic<TieHead, TieHeadOp>(
         c, M, GroupIn{ck[cc], M},
