@@ -212,7 +212,7 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
     u32 *keys[2] = {g0.get(), g1.get()};
     u32 *vals[2] = {nullptr, nullptr};
     c.sort_tag = "gap:";
-    int cur = radix_sort_u32(c, keys, vals, total, 0, bits);
+    int cur = radix_sort_u32(c, keys, vals, total, 0, bits, 2);
     c.sort_tag = "";
     G.S = DBuf<u32>(c, m + 1);
     HIP_CHECK(hipMemsetAsync(G.S.get(), 0, (m + 1) * 4, c.stream));

@@ -159,9 +159,10 @@ void scan_inclusive_max_u32(Ctx &c, const u32 *in, u32 *out, size_t n);
 // Stable LSD radix sort of n (key, val) pairs on key bits [begin_bit,end_bit).
 // keys[0]/vals[0] hold the input; the other pair is scratch of the same size.
 // vals may be {nullptr,nullptr} for keys only.  Returns which pair (0 or 1)
-// holds the result.  n < 2^32.
-int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
-int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
+// holds the result.  n < 2^32.  `use` picks a kernel instantiation named after
+// the caller (0 leaf sort, 1 refinement rounds and tests, 2 gap histogram).
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
+int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------
 // a partial BWT resident on the device (include/bwt.h:122-149 of the reference)

@@ -23,7 +23,9 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES; // 1024 consecutive keys per wave
 
-template <class K>
+// USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
+// rounds, 2 gap histogram), so that a profiler lists their launches apart.
+template <class K, int USE>
 __global__ void __launch_bounds__(RS_THREADS)
     k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk) {
   __shared__ u32 cnt[RS_WAVES][256];
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(RS_THREADS)
   counts[(size_t)tid * nblk + blockIdx.x] = tot;
 }
 
-template <class K, bool HAS_VALS>
+template <class K, bool HAS_VALS, int USE>
 __global__ void __launch_bounds__(RS_THREADS)
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(RS_THREADS)
   }
 }
 
-template <class K>
+template <class K, int USE>
 static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
   if (n == 0 || end_bit <= begin_bit) return 0;
   if (n >= (1ull << 32)) fail(BWT_HIP_EINVAL, "radix sort: %zu elements exceed 2^32-1", n);
@@ -136,7 +138,7 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
     {
       KernelTimer kt(c, (std::string(c.sort_tag) + (sizeof(K) == 8 ? "k_rs_hist_u64" : "k_rs_hist_u32")).c_str(),
                      (double)n * sizeof(K));
-      hipLaunchKernelGGL((k_rs_hist<K>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur], n, shift, mask,
+      hipLaunchKernelGGL((k_rs_hist<K, USE>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur], n, shift, mask,
                          counts.get(), nblk);
       HIP_CHECK(hipGetLastError());
     }
@@ -146,10 +148,10 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
                                       : (has_vals ? "k_rs_scatter_u32_pairs" : "k_rs_scatter_u32_keys");
       KernelTimer kt(c, (std::string(c.sort_tag) + nm).c_str(), (double)n * 2 * (sizeof(K) + (has_vals ? 4 : 0)));
       if (has_vals)
-        hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+        hipLaunchKernelGGL((k_rs_scatter<K, true, USE>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
                            vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk);
       else
-        hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+        hipLaunchKernelGGL((k_rs_scatter<K, false, USE>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
                            (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(),
                            nblk);
       HIP_CHECK(hipGetLastError());
@@ -159,12 +161,14 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
   return cur;
 }
 
-int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
-  return radix_sort_impl<u64>(c, keys, vals, n, begin_bit, end_bit);
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use) {
+  if (use == 0) return radix_sort_impl<u64, 0>(c, keys, vals, n, begin_bit, end_bit);
+  return radix_sort_impl<u64, 1>(c, keys, vals, n, begin_bit, end_bit);
 }
 
-int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
-  return radix_sort_impl<u32>(c, keys, vals, n, begin_bit, end_bit);
+int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use) {
+  if (use == 2) return radix_sort_impl<u32, 2>(c, keys, vals, n, begin_bit, end_bit);
+  return radix_sort_impl<u32, 1>(c, keys, vals, n, begin_bit, end_bit);
 }
 
 }  // namespace bwtamd

@@ -228,7 +228,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
     int passes = (64 - low_bit + 7) / 8;
     Phase ph(c, "leaf_radix_sort", (double)N * passes * 32);
     c.sort_tag = "leaf:";
-    cur = radix_sort_u64(c, keys, vals, N, low_bit, 64);
+    cur = radix_sort_u64(c, keys, vals, N, low_bit, 64, 0);
     c.sort_tag = "";
   }
   u32 *sa = vals[cur];

@@ -1,0 +1,68 @@
+/* device_session.h -- the process-wide link between the bwt:: header API and
+   libbwt_hip.so: one device context, and the text it currently holds.
+
+   The reference needs nothing like this (it has no device).  The header API
+   passes `const alpha_t * T, idx_t n` to every call; the session uploads T the
+   first time it sees a (pointer, length, content signature) and reuses the
+   device copy afterwards.  Failures of the C-ABI are reported the way the
+   reference reports failures: message on stderr, abort() (include/util.h:26-36
+   of the reference). */
+#pragma once
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "bwt_hip.h"
+#include "typedefs.h"
+
+namespace bwt {
+
+  inline void hip_ok_(int rc, const char * what, const char * file, int line) {
+    if (rc != 0) {
+      fprintf(stderr, "error:%s:%d: %s failed (%d): %s\n", file, line, what, rc, bwt_hip_last_error());
+      abort();
+    }
+  }
+#define bwt_hip_ok(call) ::bwt::hip_ok_((call), #call, __FILE__, __LINE__)
+
+  struct device_session {
+    bwt_hip_ctx * ctx;
+    int device;
+    const alpha_t * T;
+    idx_t n;
+    uint64_t sig;
+
+    device_session() : ctx(0), device(-1), T(0), n(0), sig(0) {}
+    ~device_session() { if (ctx) bwt_hip_destroy(ctx); }
+
+    static device_session & get() { static device_session s; return s; }
+
+    bwt_hip_ctx * context(int dev) {
+      if (ctx && device != dev) { bwt_hip_destroy(ctx); ctx = 0; T = 0; }
+      if (!ctx) { bwt_hip_ok(bwt_hip_create(dev, &ctx)); device = dev; }
+      return ctx;
+    }
+
+    /* FNV-1a over the ends and a stride of the text: cheap, and enough to notice a reused buffer */
+    static uint64_t signature(const alpha_t * T, idx_t n) {
+      uint64_t h = 0xcbf29ce484222325ull;
+      idx_t step = n / 4096 + 1;
+      for (idx_t i = 0; i < n; i += step) { h ^= T[i]; h *= 0x100000001b3ull; }
+      for (idx_t i = (n > 4096 ? n - 4096 : 0); i < n; i++) { h ^= T[i]; h *= 0x100000001b3ull; }
+      return h ^ (uint64_t)n;
+    }
+
+    /* makes the context hold T[0:n); `force` uploads even if it looks unchanged */
+    bwt_hip_ctx * with_text(const alpha_t * T_, idx_t n_, int dev, bool force = false) {
+      bwt_hip_ctx * c = context(dev);
+      uint64_t s = signature(T_, n_);
+      if (force || T != T_ || n != n_ || sig != s) {
+        bwt_hip_ok(bwt_hip_set_text(c, T_, n_));
+        T = T_; n = n_; sig = s;
+      }
+      return c;
+    }
+  };
+
+}

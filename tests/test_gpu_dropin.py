@@ -1,0 +1,68 @@
+"""GPU tests of the drop-in boundary: C++ programs written against the bwt:: header API.
+
+tools/bin/* are this repo's own programs (tools/Makefile).  oracle/_ref/dropin/* are the REFERENCE's own
+programs (src/simplest_example.cc, src/pmbwt.cc, src/test/test_*.cc) compiled, unmodified and where they lie,
+against this repo's include/ and linked to libbwt_hip.so (oracle/Makefile, target dropin); they exist only
+where the reference tree was mounted at build time and are skipped otherwise.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OWN = os.path.join(ROOT, "tools", "bin")
+REF = os.path.join(ROOT, "oracle", "_ref", "dropin")
+
+pytestmark = pytest.mark.gpu
+
+
+def run(path, *args, timeout=170):
+    p = subprocess.run([path] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    return p.returncode, p.stdout.decode("latin1")
+
+
+def need(path):
+    if not os.path.exists(path):
+        pytest.skip("%s not built" % os.path.relpath(path, ROOT))
+    return path
+
+
+def test_own_dropin_check():
+    rc, out = run(need(os.path.join(OWN, "dropin_check")))
+    assert rc == 0 and "ALL OK" in out, out[-2000:]
+
+
+def test_own_simplest_example():
+    rc, out = run(need(os.path.join(OWN, "simplest_example")))
+    assert rc == 0 and "bwt:   ard$rcaaaabb" in out, out
+
+
+@pytest.mark.parametrize("args", [
+    ["100000"],                                                           # the reference CLI's defaults: 'a'..'z'
+    ["--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1", "-m", "3.0", "2000000"],
+    ["--generator", "nrand48", "--alpha_max", "z", "-t", "5000", "--ssa_n_samples", "300", "--build_gap_segment_sz", "77", "200000"],
+    ["--stat_level", "1", "--mstat_level", "1", "--repeat", "2", "50000"],
+])
+def test_own_cli_round_trip(args):
+    rc, out = run(need(os.path.join(OWN, "pmbwt")), *args)
+    assert rc == 0 and "checking result ... OK" in out and "NG" not in out, out[-2000:]
+    assert "clocks to build bwt for" in out  # the line the reference prints, include/bwt.h:881
+
+
+def test_reference_simplest_example_unmodified():
+    rc, out = run(need(os.path.join(REF, "simplest_example")))
+    assert rc == 0 and "ipssm" in out and "pissii" in out, out
+
+
+@pytest.mark.parametrize("args", [["100000"], ["--check", "1", "-m", "3", "1000000"], ["--stat_level", "1", "30000"]])
+def test_reference_cli_unmodified(args):
+    rc, out = run(need(os.path.join(REF, "pmbwt")), *args)
+    assert rc == 0 and "checking result ... OK" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("prog,args", [("test_leaf", [20000, 5]), ("test_merge", [20000, 5]), ("test_ssa", [3000, 3]),
+                                       ("test_rec", [20000, 3]), ("test_suffix_array", []), ("test_wavelet_matrix", [])])
+def test_reference_tests_unmodified(prog, args):
+    rc, out = run(need(os.path.join(REF, prog)), *args)
+    assert rc == 0 and "NG" not in out, out[-2000:]
