@@ -7,8 +7,9 @@ already resident in HBM; the result L stays in HBM.  Metric: Mbase/s = (n-1) / s
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n N_CHARS] [--sigma S] [--leaves P]
 
 N = 1 runs the configuration the headline metric is quoted on for one GPU: random DNA, n = 1e9, two leaves
-of 5e8 and one gap-array merge.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the text of
-N * 1e9 / 2 ... see DESIGN.md "Multi-GPU": the ranks split the leaves of ONE text and merge pairwise over RCCL.
+of 5e8 and one gap-array merge.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the ranks share
+ONE text of 3.1e9 symbols: each builds the leaves of its part and the blocks are merged pairwise over RCCL
+send/recv (bwt_amd/multi_gpu.py); that is strong scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,14 +52,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10 ** 9)
+    ap.add_argument("--n", type=int, default=None, help="text length (default 1e9 on one GPU, 3.1e9 on several)")
     ap.add_argument("--sigma", type=int, default=4)
-    ap.add_argument("--leaves", type=int, default=2, help="leaves per GPU (power of two)")
+    ap.add_argument("--leaves", type=int, default=None, help="leaves (power of two; default 2 on one GPU, one per GPU on several)")
     ap.add_argument("--ssa_n_samples", type=int, default=0)
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--cpu_n", type=int, default=10 ** 7, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-timers", action="store_true")
     args = ap.parse_args()
+    args.n_given, args.leaves_given = args.n is not None, args.leaves is not None
+    if args.n is None:
+        args.n = 10 ** 9
+    if args.leaves is None:
+        args.leaves = 2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

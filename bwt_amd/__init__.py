@@ -54,6 +54,8 @@ def lib():
         "bwt_hip_rec": [vp, i64, i64, i64, i64, i64, C.POINTER(vp)],
         "bwt_hip_pmbwt": [vp, i64, i64, i64, C.POINTER(vp)],
         "bwt_hip_block_upload": [vp, i64, i64, _u8p, i64, i64, _i64p, _i64p, i64, C.POINTER(vp)],
+        "bwt_hip_block_export_device": [vp, vp, vp, vp, vp],
+        "bwt_hip_block_import_device": [vp, i64, i64, vp, i64, i64, vp, vp, i64, C.POINTER(vp)],
         "bwt_hip_block_info": [vp, _i64p, _i64p, _i64p, _i64p, C.POINTER(i32), _i64p],
         "bwt_hip_block_get_L": [vp, vp, _u8p],
         "bwt_hip_block_L_device": [vp, C.POINTER(vp)],
@@ -171,6 +173,13 @@ class Context:
                                         len(sr), C.byref(h)))
         return self._blk(h)
 
+    def import_block_device(self, a, b, L_ptr, s_rank, e_rank, rank_ptr, pos_ptr, n_samples):
+        """Block from device buffers (raw addresses): uint8 L[b-a], int64 ranks / positions."""
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_block_import_device(self._h, a, b, C.c_void_p(L_ptr), s_rank, e_rank, C.c_void_p(rank_ptr),
+                                               C.c_void_p(pos_ptr), n_samples, C.byref(h)))
+        return self._blk(h)
+
     def leaf_sa(self, a, b):
         SA = np.empty(b - a, dtype=np.int64)
         _chk(lib().bwt_hip_leaf_sa(self._h, a, b, _p(SA, _i64p)))
@@ -270,6 +279,11 @@ class Block:
         p = C.c_void_p()
         _chk(lib().bwt_hip_block_L_device(self._h, C.byref(p)))
         return p.value
+
+    def export_device(self, L_ptr, rank_ptr, pos_ptr):
+        """Copies L and the samples into device buffers given by raw addresses."""
+        _chk(lib().bwt_hip_block_export_device(self.ctx._h, self._h, C.c_void_p(L_ptr), C.c_void_p(rank_ptr),
+                                               C.c_void_p(pos_ptr)))
 
     def samples(self):
         r = np.empty(self.n_samples, dtype=np.int64)

@@ -267,6 +267,72 @@ int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *
   API_END
 }
 
+__global__ void k_widen_samples(const u32 *__restrict__ r, const u32 *__restrict__ p, u32 n, i64 a,
+                                i64 *__restrict__ ro, i64 *__restrict__ po) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    ro[k] = a + (i64)r[k];
+    po[k] = (i64)p[k];
+  }
+}
+
+__global__ void k_narrow_samples(const i64 *__restrict__ r, const i64 *__restrict__ p, u32 n, i64 a,
+                                 u32 *__restrict__ ro, u32 *__restrict__ po) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    ro[k] = (u32)(r[k] - a);
+    po[k] = (u32)p[k];
+  }
+}
+
+int bwt_hip_block_export_device(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, uint8_t *L_dev, int64_t *rank_dev,
+                                int64_t *pos_dev) {
+  API_BEGIN
+  need(ctx && blk_ && L_dev && rank_dev && pos_dev, "ctx, blk, L_dev, samp_rank_dev, samp_pos_dev");
+  Ctx &c = ctx->c;
+  const Block *blk = as_block(blk_);
+  HIP_CHECK(hipSetDevice(c.device));
+  HIP_CHECK(hipMemcpyAsync(L_dev, blk->L.get(), (size_t)blk->len(), hipMemcpyDeviceToDevice, c.stream));
+  if (blk->n_samp > 0) {
+    hipLaunchKernelGGL(k_widen_samples, dim3(ceil_div(blk->n_samp, 256)), dim3(256), 0, c.stream,
+                       blk->samp_rank.get(), blk->samp_pos.get(), (u32)blk->n_samp, blk->a, rank_dev, pos_dev);
+    HIP_CHECK(hipGetLastError());
+  }
+  c.sync();
+  API_END
+}
+
+int bwt_hip_block_import_device(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *L_dev, int64_t s_rank,
+                                int64_t e_rank, const int64_t *rank_dev, const int64_t *pos_dev, int64_t ns,
+                                bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && L_dev && out && rank_dev && pos_dev, "ctx, L_dev, samp_rank_dev, samp_pos_dev, out");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  need(a >= 0 && a < b && b <= c.n, "0 <= a < b <= n");
+  need(s_rank >= a && s_rank < b && e_rank >= a && e_rank < b, "ranks inside [a,b)");
+  need(ns >= 1, "n_samples >= 1");
+  HIP_CHECK(hipSetDevice(c.device));
+  std::unique_ptr<Block> blk(new Block());
+  blk->a = a;
+  blk->b = b;
+  blk->s_rank = s_rank - a;
+  blk->e_rank = e_rank - a;
+  blk->L = DBuf<u8>(c, (size_t)(b - a));
+  blk->samp_rank = DBuf<u32>(c, (size_t)ns);
+  blk->samp_pos = DBuf<u32>(c, (size_t)ns);
+  blk->n_samp = ns;
+  HIP_CHECK(hipMemcpyAsync(blk->L.get(), L_dev, (size_t)(b - a), hipMemcpyDeviceToDevice, c.stream));
+  hipLaunchKernelGGL(k_narrow_samples, dim3(ceil_div(ns, 256)), dim3(256), 0, c.stream, rank_dev, pos_dev, (u32)ns, a,
+                     blk->samp_rank.get(), blk->samp_pos.get());
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  blk->e_char = *(u8 *)c.h_scalars;
+  *out = as_handle(blk.release());
+  API_END
+}
+
 void bwt_hip_block_free(bwt_hip_ctx *ctx, bwt_hip_block *blk) {
   (void)ctx;
   delete as_block(blk);

@@ -1,0 +1,195 @@
+"""One text, several GPUs: leaves sharded over the ranks, merge tree over send/recv.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Every rank holds the whole text
+(a 3.1 Gbp text is 3.1 GB of 288 GB), because suffix comparisons and LF-mapping chains read it at arbitrary
+positions.  The recursion tree of bwt::bwt_rec (reference include/bwt.h:854-865: split at (a+b)/2) is cut at depth
+log2(world): rank r builds the subtree whose range is the r-th of those world ranges, entirely on its own GPU.  Then,
+level by level, the owner of a right sibling sends its block -- L[a:b), the samples and four scalars -- to the owner
+of the left sibling, which merges (include/bwt.h:791-847).  The result is bit-identical to the single-GPU recursion
+because it is the same tree.  The final block ends on rank 0.
+
+torch is plumbing here: tensors as send/recv buffers, and the process group.  All BWT work is in libbwt_hip.so.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def split_ranges(a, b, depth):
+    """The 2^depth ranges that bwt_rec's midpoint splitting of [a,b) reaches at `depth`."""
+    if depth == 0:
+        return [(a, b)]
+    c = (a + b) // 2
+    return split_ranges(a, c, depth - 1) + split_ranges(c, b, depth - 1)
+
+
+def leaf_threshold(n, total_leaves):
+    """A bwt_rec_threshold for which midpoint splitting of [0,n) stops exactly at `total_leaves` equal-depth leaves."""
+    depth = total_leaves.bit_length() - 1
+    assert 1 << depth == total_leaves, "leaf count must be a power of two"
+    sizes = [b - a for a, b in split_ranges(0, n, depth)]
+    th = max(sizes)
+    if depth > 0:
+        parents = [b - a for a, b in split_ranges(0, n, depth - 1)]
+        assert min(parents) > th, "n too small for %d leaves" % total_leaves
+    return th
+
+
+def tree_levels(world):
+    """[(stride, [(dst, src), ...]), ...]: at each level the owner src of a right sibling sends to dst = src - stride."""
+    levels = []
+    stride = 1
+    while stride < world:
+        pairs = [(r, r + stride) for r in range(0, world, 2 * stride) if r + stride < world]
+        levels.append((stride, pairs))
+        stride *= 2
+    return levels
+
+
+class HipOps:
+    """Block operations on one GPU through the C-ABI, and (de)serialisation of a block for transport."""
+
+    def __init__(self, ctx, ns, seg, device_buffers, torch_device=None):
+        self.ctx, self.ns, self.seg = ctx, ns, seg
+        self.device_buffers = device_buffers  # True: tensors in HBM (nccl); False: host tensors (gloo)
+        self.torch_device = torch_device
+
+    def rec(self, a, b, th):
+        return self.ctx.rec(a, b, th, self.ns, self.seg)
+
+    def merge(self, l, r):
+        return self.ctx.merge(l, r, self.ns, self.seg)
+
+    def header(self, blk):
+        return [blk.a, blk.b, blk.s_rank, blk.e_rank, blk.n_samples]
+
+    def pack(self, blk):
+        import torch
+        if self.device_buffers:
+            Lt = torch.empty(blk.b - blk.a, dtype=torch.uint8, device=self.torch_device)
+            rt = torch.empty(blk.n_samples, dtype=torch.int64, device=self.torch_device)
+            pt = torch.empty(blk.n_samples, dtype=torch.int64, device=self.torch_device)
+            torch.cuda.synchronize()
+            blk.export_device(Lt.data_ptr(), rt.data_ptr(), pt.data_ptr())
+            return Lt, rt, pt
+        r, p = blk.samples()
+        return torch.from_numpy(blk.L), torch.from_numpy(r), torch.from_numpy(p)
+
+    def empty(self, hdr):
+        import torch
+        a, b, _, _, ns = hdr
+        dev = self.torch_device if self.device_buffers else "cpu"
+        return (torch.empty(b - a, dtype=torch.uint8, device=dev), torch.empty(ns, dtype=torch.int64, device=dev),
+                torch.empty(ns, dtype=torch.int64, device=dev))
+
+    def unpack(self, hdr, Lt, rt, pt):
+        a, b, s_rank, e_rank, ns = hdr
+        if self.device_buffers:
+            import torch
+            torch.cuda.synchronize()
+            return self.ctx.import_block_device(a, b, Lt.data_ptr(), s_rank, e_rank, rt.data_ptr(), pt.data_ptr(), ns)
+        return self.ctx.upload_block(a, b, Lt.numpy(), s_rank, e_rank, rt.numpy(), pt.numpy())
+
+
+def send_block(ops, blk, dst, dist, hdr_device):
+    import torch
+    hdr = torch.tensor(ops.header(blk), dtype=torch.int64, device=hdr_device)
+    dist.send(hdr, dst)
+    for t in ops.pack(blk):
+        dist.send(t, dst)
+
+
+def recv_block(ops, src, dist, hdr_device):
+    import torch
+    hdr = torch.empty(5, dtype=torch.int64, device=hdr_device)
+    dist.recv(hdr, src)
+    h = [int(x) for x in hdr.cpu().tolist()]
+    bufs = ops.empty(h)
+    for t in bufs:
+        dist.recv(t, src)
+    return ops.unpack(h, *bufs)
+
+
+def pmbwt_tree(ops, rank, world, n, leaves_per_rank, dist, hdr_device="cpu", free=lambda b: b.free()):
+    """The whole BWT of [0,n) over `world` ranks.  Returns the final block on rank 0 and None elsewhere."""
+    depth = world.bit_length() - 1
+    assert 1 << depth == world, "world size must be a power of two"
+    th = leaf_threshold(n, world * leaves_per_rank)
+    a, b = split_ranges(0, n, depth)[rank]
+    blk = ops.rec(a, b, th)
+    for stride, pairs in tree_levels(world):
+        for dst, src in pairs:
+            if rank == src:
+                send_block(ops, blk, dst, dist, hdr_device)
+                free(blk)
+                blk = None
+            elif rank == dst:
+                rblk = recv_block(ops, src, dist, hdr_device)
+                blk = ops.merge(blk, rblk)
+    return blk
+
+
+def bench_main(args, rank, local_rank, world):
+    """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs."""
+    import torch
+    import torch.distributed as dist
+    import bwt_amd
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    n = args.n if args.n_given else 3100000000
+    ctx = bwt_amd.Context(local_rank)
+    ctx.gen_text(n, 42, args.sigma)
+    lpr = max(1, args.leaves // 2) if args.leaves_given else 1
+    total_leaves = world * lpr
+    depth = total_leaves.bit_length() - 1
+    ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
+    ops = HipOps(ctx, ns, args.seg, True, dev)
+
+    def step():
+        blk = pmbwt_tree(ops, rank, world, n, lpr, dist, hdr_device=dev)
+        ctx.sync()
+        return blk
+
+    for _ in range(args.warmup):
+        blk = step()
+        if blk is not None:
+            blk.free()
+    ctx.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last.free()
+        last = step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item()) / args.steps
+    if rank == 0:
+        th = leaf_threshold(n, total_leaves)
+        out = {
+            "metric": "BWT build Mbase/s end-to-end", "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
+            "config": {"workload": "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0"
+                                   % (n, total_leaves, world),
+                       "n": n, "sigma": args.sigma, "leaves": total_leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
+                       "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True,
+                       "parallelism": "leaf-sharded x%d, pairwise merge tree" % world},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if last is not None:
+        last.free()
+    ctx.close()
+    dist.destroy_process_group()

@@ -93,6 +93,18 @@ int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *
                          int64_t e_rank, const int64_t *samp_rank, const int64_t *samp_pos, int64_t n_samples,
                          bwt_hip_block **out);
 
+/* The same two transfers with DEVICE buffers owned by the caller (for example
+   tensors that RCCL sends between GPUs): export copies L[a:b) and the samples
+   (absolute ranks, positions) out of a block; import builds a block from such
+   buffers.  The buffers must not be in use by other streams during the call;
+   the copies are complete when the call returns.  No counterpart in the
+   reference (it has one address space). */
+int bwt_hip_block_export_device(bwt_hip_ctx *ctx, const bwt_hip_block *blk, uint8_t *L_dev, int64_t *samp_rank_dev,
+                                int64_t *samp_pos_dev);
+int bwt_hip_block_import_device(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *L_dev, int64_t s_rank,
+                                int64_t e_rank, const int64_t *samp_rank_dev, const int64_t *samp_pos_dev,
+                                int64_t n_samples, bwt_hip_block **out);
+
 /* bwt::fini (include/bwt.h:174-182) */
 void bwt_hip_block_free(bwt_hip_ctx *ctx, bwt_hip_block *blk);
 

@@ -1,0 +1,62 @@
+"""CPU tests of the multi-rank path: range/threshold arithmetic, the merge-tree schedule, and a world_size-2 run
+over gloo in which the CPU oracle stands in for the GPU (transport and schedule are what is tested)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bwt_amd import multi_gpu
+from oracle import Oracle, gen_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_ranges_follow_midpoint_recursion():
+    # include/bwt.h:860 of the reference: c = (a + b) / 2
+    assert multi_gpu.split_ranges(0, 10, 0) == [(0, 10)]
+    assert multi_gpu.split_ranges(0, 10, 1) == [(0, 5), (5, 10)]
+    assert multi_gpu.split_ranges(0, 11, 2) == [(0, 2), (2, 5), (5, 8), (8, 11)]
+    r = multi_gpu.split_ranges(0, 3100000000, 3)
+    assert r[0][0] == 0 and r[-1][1] == 3100000000 and all(x[1] == y[0] for x, y in zip(r, r[1:]))
+
+
+@pytest.mark.parametrize("n,leaves", [(1000, 2), (100001, 8), (10 ** 9, 2), (3100000000, 8), (3100000000, 16)])
+def test_leaf_threshold_reproduces_the_tree(n, leaves):
+    th = multi_gpu.leaf_threshold(n, leaves)
+
+    def rec(a, b):
+        return [(a, b)] if b - a <= th else rec(a, (a + b) // 2) + rec((a + b) // 2, b)
+    assert rec(0, n) == multi_gpu.split_ranges(0, n, leaves.bit_length() - 1)
+
+
+def test_tree_levels():
+    assert multi_gpu.tree_levels(1) == []
+    assert multi_gpu.tree_levels(2) == [(1, [(0, 1)])]
+    assert multi_gpu.tree_levels(8) == [(1, [(0, 1), (2, 3), (4, 5), (6, 7)]), (2, [(0, 2), (4, 6)]), (4, [(0, 4)])]
+
+
+def _launch(world, extra, out, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+           os.path.join(ROOT, "tests", "mgpu_worker.py"), "--out", out] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+
+
+@pytest.mark.parametrize("world,lpr", [(2, 2), (4, 1)])
+def test_gloo_tree_with_oracle_blocks(tmp_path, world, lpr):
+    n, ns, seg = 20000, 200, 64
+    out = str(tmp_path / "res.npz")
+    _launch(world, ["--ops", "oracle", "--text_len", str(n), "--lpr", str(lpr), "--ns", str(ns), "--seg", str(seg)], out)
+    res = np.load(out)
+    T = gen_text(n, 42, 4)
+    th = multi_gpu.leaf_threshold(n, world * lpr)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=4, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (res["L"] == ob.L).all()
+    assert (int(res["s_rank"]), int(res["e_rank"])) == (ob.s_rank, ob.e_rank)
+    r, p = ob.samples()
+    assert (res["rank"] == r).all() and (res["pos"] == p).all()
