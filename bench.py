@@ -76,7 +76,7 @@ def main():
             sys.exit(2)
 
     import bwt_amd
-    if world > 1:
+    if world > 1 or os.environ.get("BWT_BENCH_FORCE_DIST"):  # the env switch rehearses the N > 1 leg on one GPU
         from bwt_amd import multi_gpu
         return multi_gpu.bench_main(args, rank, local_rank, world)
 

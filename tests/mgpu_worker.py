@@ -54,7 +54,39 @@ class OracleOps:
         return blk
 
 
+def export_import_check():
+    """Single process: a block goes out through torch device tensors and comes back; merge results must not change.
+    torch is imported before the HIP library is loaded, so both use the one HIP runtime torch ships."""
+    import torch
+    import bwt_amd
+    from oracle import gen_text
+    n = 50000
+    T = gen_text(n, 5, 4)
+    ctx = bwt_amd.Context(0)
+    ctx.set_text(T)
+    a, b = 100, 49000
+    c = (a + b) // 2  # where bwt_rec splits
+    lb, rb = ctx.leaf(a, c, 300), ctx.leaf(c, b, 300)
+    dev = torch.device("cuda", 0)
+    Lt = torch.empty(b - c, dtype=torch.uint8, device=dev)
+    rt = torch.empty(rb.n_samples, dtype=torch.int64, device=dev)
+    pt = torch.empty(rb.n_samples, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    rb.export_device(Lt.data_ptr(), rt.data_ptr(), pt.data_ptr())
+    r, p = rb.samples()
+    assert (Lt.cpu().numpy() == rb.L).all() and (rt.cpu().numpy() == r).all() and (pt.cpu().numpy() == p).all()
+    rb2 = ctx.import_block_device(c, b, Lt.data_ptr(), rb.s_rank, rb.e_rank, rt.data_ptr(), pt.data_ptr(), rb.n_samples)
+    ref = ctx.rec(a, b, c - a + 1, 300)  # the same two leaves and merge in one call
+    m = ctx.merge(lb, rb2, 300)
+    assert (m.L == ref.L).all() and (m.s_rank, m.e_rank) == (ref.s_rank, ref.e_rank)
+    for x, y in zip(m.samples(), ref.samples()):
+        assert (x == y).all()
+    print("EXPORT_IMPORT_OK")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "export_import":
+        return export_import_check()
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", default="hip")
     ap.add_argument("--text_len", dest="n", type=int, default=100000)

@@ -1,6 +1,8 @@
 """GPU tests of the multi-rank path on a one-GPU box: block transport through device buffers, and a two-rank
 merge tree (both ranks on GPU 0, transport over gloo) against the single-process build."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,30 +12,17 @@ from tests.gpu_util import ctx  # noqa: F401
 from tests.test_multi_gpu_cpu import _launch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-def test_block_export_import_through_device_tensors(ctx):
-    import torch
-    n = 50000
-    T = gen_text(n, 5, 4)
-    ctx.set_text(T)
-    a, c, b = 100, 20000, 49000
-    lb, rb = ctx.leaf(a, c, 300), ctx.leaf(c, b, 300)
-    dev = torch.device("cuda", 0)
-    Lt = torch.empty(b - c, dtype=torch.uint8, device=dev)
-    rt = torch.empty(rb.n_samples, dtype=torch.int64, device=dev)
-    pt = torch.empty(rb.n_samples, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    rb.export_device(Lt.data_ptr(), rt.data_ptr(), pt.data_ptr())
-    r, p = rb.samples()
-    assert (Lt.cpu().numpy() == rb.L).all() and (rt.cpu().numpy() == r).all() and (pt.cpu().numpy() == p).all()
-    rb2 = ctx.import_block_device(c, b, Lt.data_ptr(), rb.s_rank, rb.e_rank, rt.data_ptr(), pt.data_ptr(), rb.n_samples)
-    ref = ctx.rec(a, b, c - a + 1, 300)  # the same two leaves and merge in one call
-    m = ctx.merge(lb, rb2, 300)
-    assert (m.L == ref.L).all() and (m.s_rank, m.e_rank) == (ref.s_rank, ref.e_rank)
-    for x, y in zip(m.samples(), ref.samples()):
-        assert (x == y).all()
+def test_block_export_import_through_device_tensors():
+    # runs in a process of its own: torch must be imported before libbwt_hip.so is loaded, so that the
+    # library binds to the HIP runtime torch ships instead of bringing a second one into the process
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mgpu_worker.py"), "export_import"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=550, cwd=ROOT)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "EXPORT_IMPORT_OK" in out, out[-3000:]
 
 
 @pytest.mark.timeout(900)
