@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=None, help="text length (default 1e9 on one GPU, 3.1e9 on several)")
+    ap.add_argument("--text_len", "--n", dest="n", type=int, default=None, help="text length (default 1e9 on one GPU, 3.1e9 on several)")
     ap.add_argument("--sigma", type=int, default=4)
     ap.add_argument("--leaves", type=int, default=None, help="leaves (power of two; default 2 on one GPU, one per GPU on several)")
     ap.add_argument("--ssa_n_samples", type=int, default=0)

@@ -92,14 +92,15 @@ static void drop_text(Ctx &c) {
 }
 
 static void adopt_text(Ctx &c, const u8 *dT, i64 n) {
-  int max_sym = 0, last = 0;
+  int max_sym = 0, min_sym = 0, last = 0;
   i64 n_zero = 0;
-  text_stats(c, dT, n, &max_sym, &n_zero, &last);
+  text_stats(c, dT, n, &max_sym, &min_sym, &n_zero, &last);
   if (last != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", last);
   if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
   c.T = dT;
   c.n = n;
   c.max_sym = max_sym;
+  c.min_sym = min_sym;
   int bits = 1;
   while ((max_sym >> bits) != 0) bits++;
   c.sym_bits = bits;
@@ -175,10 +176,7 @@ int bwt_hip_get_text(bwt_hip_ctx *ctx, uint8_t *T_host) {
 // ---------------------------------------------------------------------------
 // pipeline
 // ---------------------------------------------------------------------------
-static Block *do_leaf(Ctx &c, i64 a, i64 b, i64 ns) {
-  DBuf<u32> sa = leaf_suffix_array(c, a, b);
-  return leaf_from_sa(c, a, b, sa.get(), ns);
-}
+static Block *do_leaf(Ctx &c, i64 a, i64 b, i64 ns) { return build_leaf(c, a, b, ns); }
 
 static Block *do_merge(Ctx &c, Block *l, Block *r, i64 ns, i64 seg) {
   std::unique_ptr<Block> L(l), R(r);

@@ -156,34 +156,38 @@ void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma) {
   HIP_CHECK(hipGetLastError());
 }
 
-// out[0] = max symbol, out[1] = number of zeros (saturating at 2^31)
+// out[0] = max symbol, out[1] = number of zeros, out[2] = 255 - (smallest non-zero symbol)
 __global__ void k_text_stats(const u8 *T, u64 n, u32 *out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 stride = (u64)gridDim.x * blockDim.x;
-  u32 mx = 0, nz = 0;
+  u32 mx = 0, nz = 0, inv_mn = 0;
   for (; i < n; i += stride) {
     u32 v = T[i];
     mx = max(mx, v);
     nz += (v == 0);
+    if (v) inv_mn = max(inv_mn, 255u - v);
   }
   mx = wave_reduce_max(mx);
   nz = wave_reduce_sum(nz);
+  inv_mn = wave_reduce_max(inv_mn);
   if ((threadIdx.x & 63) == 0) {
     atomicMax(&out[0], mx);
     atomicAdd(&out[1], nz);
+    atomicMax(&out[2], inv_mn);
   }
 }
 
-void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, i64 *n_zero, int *last) {
-  HIP_CHECK(hipMemsetAsync(c.d_scalars, 0, 8, c.stream));
+void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last) {
+  HIP_CHECK(hipMemsetAsync(c.d_scalars, 0, 12, c.stream));
   u32 blocks = (u32)std::min<u64>(ceil_div(n, 256 * 16), (u64)c.n_cu * 16);
   hipLaunchKernelGGL(k_text_stats, dim3(blocks), dim3(256), 0, c.stream, dT, (u64)n, c.d_scalars);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.d_scalars, 8, hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.d_scalars, 12, hipMemcpyDeviceToHost, c.stream));
   u8 lastc = 0;
-  HIP_CHECK(hipMemcpyAsync(&c.h_scalars[2], dT + n - 1, 1, hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipMemcpyAsync(&c.h_scalars[3], dT + n - 1, 1, hipMemcpyDeviceToHost, c.stream));
   c.sync();
-  lastc = *(u8 *)&c.h_scalars[2];
+  lastc = *(u8 *)&c.h_scalars[3];
+  *min_sym = c.h_scalars[0] ? 255 - (int)c.h_scalars[2] : 0;
   *max_sym = (int)c.h_scalars[0];
   *n_zero = (i64)c.h_scalars[1];
   *last = lastc;

@@ -72,9 +72,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
         lo = hi = 0;
         continue;
       }
-      u32 b = base_s[c];
-      u32 klo = b + wm_walk(P.wm, c, lo);
-      u32 khi = (hi == lo) ? klo : b + wm_walk(P.wm, c, hi);
+      u32 klo = wm_lf(P.wm, base_s, c, lo);
+      u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
       if (c == e_char && khi >= e_rank) {
         if (suffix_less(T, P.lb - 1, j)) {
           klo += (klo >= e_rank);
@@ -93,7 +92,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
   u32 step = 1;
   for (u64 j = j0; j-- > begin; step++) {
     u32 c = T[j];
-    u32 kk = base_s[c] + wm_walk(P.wm, c, g);
+    u32 kk = wm_lf(P.wm, base_s, c, g);
     if (c == e_char && kk >= e_rank) {
       if (suffix_less(T, P.lb - 1, j)) kk++;
     }
@@ -141,16 +140,6 @@ static int bits_for(u64 x) {
   return b;
 }
 
-WmView make_view(const WaveletDev &wm) {
-  WmView v;
-  v.planes = wm.planes.get();
-  v.level_words = wm.n_blk * WM_BLOCK_WORDS;
-  v.levels = wm.levels;
-  v.max_pos = (u32)(wm.n_blk * WM_BLOCK_BITS - 1);
-  for (int l = 0; l < 8; l++) v.n_zeros[l] = wm.n_zeros[l];
-  return v;
-}
-
 GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
   if (l.b != r.a) fail(BWT_HIP_EINVAL, "blocks are not adjacent: [%ld,%ld) and [%ld,%ld)", (long)l.a, (long)l.b,
                        (long)r.a, (long)r.b);
@@ -186,11 +175,11 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
   }
   P.e_char = l.e_char;
   P.e_rank = (u32)l.e_rank;
-  P.wm = make_view(l.wm);
+  P.wm = make_view(l);
   P.lf_tab = l.wm.lf_base.get();
   P.g = g0.get();
   {
-    Phase ph(c, "gap_chains", (double)rn * (l.wm.levels + 1));  // random 64-byte transactions
+    Phase ph(c, "gap_chains", (double)rn * (l.wm.levels + 1));  // random line transactions
     hipLaunchKernelGGL(k_chains, dim3(ceil_div(G.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
   }

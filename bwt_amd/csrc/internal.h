@@ -65,6 +65,7 @@ struct Ctx {
   u8 *T_owned = nullptr;
   i64 n = 0;
   int max_sym = 0;  // largest symbol in T
+  int min_sym = 0;  // smallest symbol in T besides the terminator (0 if there is none)
   int sym_bits = 0; // bits per symbol = floor(log2(max_sym)) + 1
 
   // caching allocator (sizes rounded up; freed blocks are kept for reuse)
@@ -168,11 +169,12 @@ int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 // a partial BWT resident on the device (include/bwt.h:122-149 of the reference)
 // ---------------------------------------------------------------------------
 struct WaveletDev {
-  int levels = 0;
-  u64 n_blk = 0;        // 64-byte rank blocks per level
-  DBuf<u64> planes;     // levels * n_blk * 8 words
-  u32 n_zeros[8] = {0}; // zeros per level
-  DBuf<u32> lf_base;    // 256 entries: C[c] - p_end[c]
+  int levels = 0;        // two code bits per level
+  u32 min_sym = 1;       // code = symbol - min_sym
+  u64 n_blk = 0;         // 128-byte rank blocks per level
+  DBuf<u64> planes;      // levels * n_blk * 16 words
+  u32 start[4][4] = {};  // per level: first position of each digit's bucket on the next level
+  DBuf<u32> lf_base;     // 512 entries: C[c] - p_end[c], then p_end[c]
   bool built = false;
 };
 
@@ -193,8 +195,8 @@ struct Block {
 
 // suffix_sort.hip: SA of T[a:b) in full-text suffix order, absolute positions
 DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b);
-// leaf.hip
-Block *leaf_from_sa(Ctx &c, i64 a, i64 b, const u32 *sa, i64 ns);
+// suffix_sort.hip: bwt_leaf -- the leaf's L, special ranks and samples
+Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns);
 // wavelet.hip
 void count_alphabets(Ctx &c, Block &blk);
 void build_wavelet(Ctx &c, Block &blk);
@@ -212,6 +214,8 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg, bool want_g);
 Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
 
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
-void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, i64 *n_zero, int *last);
+void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);
+struct WmView;
+WmView make_view(const Block &blk);
 
 }  // namespace bwtamd

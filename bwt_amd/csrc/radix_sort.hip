@@ -23,6 +23,15 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES; // 1024 consecutive keys per wave
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  This
+// bijection gives every XCD one contiguous range of tiles, so that the runs that
+// neighbouring tiles append to the same digit's output region meet in one L2
+// and leave it as whole lines.  Speed only: any mapping is correct.
+__device__ __forceinline__ u32 xcd_tile(u32 b, u32 nblk) {
+  u32 q = nblk >> 3, r = nblk & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
 // rounds, 2 gap histogram), so that a profiler lists their launches apart.
 template <class K, int USE>
@@ -31,14 +40,38 @@ __global__ void __launch_bounds__(RS_THREADS)
   __shared__ u32 cnt[RS_WAVES][256];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
-  const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+  const u32 tile = xcd_tile(blockIdx.x, nblk);
+  const size_t tile0 = (size_t)tile * RS_TILE;
   volatile u32 *myc = cnt[w];
-#pragma unroll 4
+  K key[RS_ITEMS];
+  const bool full = tile0 + RS_TILE <= n;
+  if (full) {  // all loads issued before the first use: 16 bytes per lane and load
+    constexpr int PER = 16 / sizeof(K);
+    const uint4 *src = reinterpret_cast<const uint4 *>(keys + tile0);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS / PER; r++) {
+      uint4 v = src[r * RS_THREADS + tid];
+      if (sizeof(K) == 8) {
+        key[2 * r] = (K)(((u64)v.y << 32) | v.x);
+        key[2 * r + 1] = (K)(((u64)v.w << 32) | v.z);
+      } else {
+        key[4 * r] = (K)v.x;
+        key[4 * r + 1] = (K)v.y;
+        key[4 * r + 2] = (K)v.z;
+        key[4 * r + 3] = (K)v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+      size_t i = tile0 + (size_t)r * RS_THREADS + tid;
+      key[r] = i < n ? keys[i] : (K)0;
+    }
+  }
+#pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    size_t i = tile0 + (size_t)r * RS_THREADS + tid;
-    bool valid = i < n;
-    K k = valid ? keys[i] : (K)0;
-    u32 d = (u32)(k >> shift) & mask;
+    bool valid = full || (tile0 + (size_t)r * RS_THREADS + tid < n);
+    u32 d = (u32)(key[r] >> shift) & mask;
     u64 peers = match_digit8(d, valid);
     if (valid && (peers & lanemask_lt()) == 0) myc[d] = myc[d] + __popcll(peers);
   }
@@ -46,7 +79,7 @@ __global__ void __launch_bounds__(RS_THREADS)
   u32 tot = 0;
 #pragma unroll
   for (int k = 0; k < RS_WAVES; k++) tot += cnt[k][tid];
-  counts[(size_t)tid * nblk + blockIdx.x] = tot;
+  counts[(size_t)tid * nblk + tile] = tot;
 }
 
 template <class K, bool HAS_VALS, int USE>
@@ -61,7 +94,8 @@ __global__ void __launch_bounds__(RS_THREADS)
   __shared__ u32 gbase[256];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+  const u32 tile = xcd_tile(blockIdx.x, nblk);
+  const size_t tile0 = (size_t)tile * RS_TILE;
   const u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
   for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
 
@@ -101,7 +135,7 @@ __global__ void __launch_bounds__(RS_THREADS)
     u32 incl = block_scan_incl<OpSum>(tot, scan_s, &all);
     u32 ds = incl - tot;
     dstart[tid] = ds;
-    gbase[tid] = offs[(size_t)tid * nblk + blockIdx.x] - ds;
+    gbase[tid] = offs[(size_t)tid * nblk + tile] - ds;
   }
   __syncthreads();
 #pragma unroll

@@ -18,6 +18,9 @@
 // past b.  Ranks of window positions p are exact to depth h while p + h <= e;
 // a leaf position that would have to look past e raises `overflow` and the
 // caller retries with a longer window (never needed when e == n).
+#include <math.h>
+#include <string.h>
+
 #include "device_utils.h"
 #include "internal.h"
 #include "scan_tmpl.h"
@@ -31,33 +34,49 @@ constexpr int KB_THREADS = 256;
 constexpr int KB_ITEMS = 16;
 constexpr int KB_TILE = KB_THREADS * KB_ITEMS;
 
-// keys[i] = symbols T[a+i .. a+i+K0) packed w bits each, first symbol highest,
-// left-aligned in 64 bits; positions >= n read as 0.  sa[i] = a + i.
+// keys[i] = | K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
+//             left-aligned | zero padding | T[a+i-1] in the low w bits |
+// Positions >= n read as 0; T[-1] is T[n-1].  Only the symbol field is sorted
+// on; the preceding symbol rides along so that the BWT symbol of every suffix
+// that round 0 already places comes out of the sorted key, not out of a random
+// read of the text.  sa[i] = a + i.
+// Each thread rolls 16 consecutive keys; they go through LDS so that the global
+// stores are contiguous per wave.
 __global__ void __launch_bounds__(KB_THREADS)
     k_build_keys(const u8 *__restrict__ T, u64 n, u64 a, u64 N, int w, int K0, u64 *__restrict__ keys,
                  u32 *__restrict__ sa) {
-  __shared__ u8 s[KB_TILE + 64];
+  __shared__ u8 s[KB_TILE + 72];        // s[k] = T[a + tile0 - 1 + k]
+  __shared__ u64 ks[KB_THREADS * 17];   // 16 keys per thread, padded to 17 against bank conflicts
   const u32 tid = threadIdx.x;
   const u64 tile0 = (u64)blockIdx.x * KB_TILE;
-  for (u32 i = tid; i < KB_TILE + 64; i += KB_THREADS) {
-    u64 p = a + tile0 + i;
-    s[i] = p < n ? T[p] : (u8)0;
+  for (u32 i = tid; i < KB_TILE + 72; i += KB_THREADS) {
+    u64 p = a + tile0 + i;  // text position + 1
+    u8 ch = 0;
+    if (p == 0) ch = T[n - 1];
+    else if (p - 1 < n) ch = T[p - 1];
+    s[i] = ch;
   }
   __syncthreads();
   const u32 t0 = tid * KB_ITEMS;
   const int used = K0 * w;
-  const u64 maskall = used == 64 ? ~0ull : ((1ull << used) - 1);
+  const u64 maskall = (1ull << used) - 1;  // used <= 64 - w < 64
   const int lsh = 64 - used;
   u64 key = 0;
-  for (int k = 0; k < K0; k++) key = (key << w) | s[t0 + k];
+  for (int k = 0; k < K0; k++) key = (key << w) | s[1 + t0 + k];
 #pragma unroll
   for (int j = 0; j < KB_ITEMS; j++) {
-    u64 idx = tile0 + t0 + j;
+    ks[tid * 17 + j] = (key << lsh) | s[t0 + j];
+    key = ((key << w) | s[1 + t0 + j + K0]) & maskall;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < KB_ITEMS; r++) {
+    u32 e = r * KB_THREADS + tid;
+    u64 idx = tile0 + e;
     if (idx < N) {
-      keys[idx] = key << lsh;
+      keys[idx] = ks[(e >> 4) * 17 + (e & 15)];
       sa[idx] = (u32)(a + idx);
     }
-    key = ((key << w) | s[t0 + j + K0]) & maskall;
   }
 }
 
@@ -78,10 +97,11 @@ struct TieHeadOp {
 struct GroupIn {
   const u64 *key;
   size_t n;
+  u64 mask;  // the key bits that count
   __device__ __forceinline__ TieHead operator()(size_t i) const {
-    u64 k = key[i];
-    bool head = (i == 0) || key[i - 1] != k;
-    bool next_head = (i + 1 == n) || key[i + 1] != k;
+    u64 k = key[i] & mask;
+    bool head = (i == 0) || (key[i - 1] & mask) != k;
+    bool next_head = (i + 1 == n) || (key[i + 1] & mask) != k;
     return TieHead{(u32)!(head && next_head), head ? (u32)(i + 1) : 0u};
   }
 };
@@ -181,16 +201,70 @@ __global__ void k_isa_fix(const u32 *__restrict__ pos, const u32 *__restrict__ g
   if (k < M) isa[pos[k] - a] = grp[k];
 }
 
+// ----------------------------------------------------------------------------
+// final pass: the leaf's BWT, special ranks and samples straight from the sorted
+// window (reference: include/bwt.h:589-609 sa_to_bwt, :294-361 sample_sa)
+// ----------------------------------------------------------------------------
+struct LeafEmit {
+  const u8 *T;
+  u64 n, a, m;
+  i64 ns;            // samples to take (already min(m, ssa_n_samples))
+  u8 *L;             // may be null: suffix array only
+  u32 *samp_rank, *samp_pos, *special;
+  u32 *sa_out;       // may be null
+  const u64 *keys;   // sorted round-0 keys of the window
+  const u32 *sa;     // sorted window positions
+  u64 N;             // window length
+  u64 sym_mask;      // symbol field of a key
+  u32 prev_mask;     // preceding-symbol field
+
+  // window rank i holds leaf rank r
+  __device__ __forceinline__ void emit(u64 r, u64 i) const {
+    u32 pos = sa[i];
+    if (sa_out) sa_out[r] = pos;
+    if (!L) return;
+    u64 k = keys[i];
+    u64 top = k & sym_mask;
+    bool tied = (i > 0 && (keys[i - 1] & sym_mask) == top) || (i + 1 < N && (keys[i + 1] & sym_mask) == top);
+    // a suffix that round 0 placed still sits next to its key; a refined one moved, so read the text
+    L[r] = tied ? (pos ? T[pos - 1] : T[n - 1]) : (u8)((u32)k & prev_mask);
+    if (pos == a) special[0] = (u32)r;          // s_rank
+    if (pos + 1 == a + m) special[1] = (u32)r;  // e_rank
+    if (m == 1) {
+      samp_rank[0] = (u32)r;
+      samp_pos[0] = pos;
+      return;
+    }
+    // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
+    // order, so the sample arrays come out sorted by position without a sort.  The two floor()
+    // expressions are the reference's own (include/bwt.h:339-340), evaluated in IEEE double as
+    // there: 64-bit integer product, one conversion, one correctly rounded division.
+    i64 rel = (i64)(pos - a);
+    i64 A = ns - 1;
+    double D = (double)(i64)(m - 1);
+    i64 x = (i64)floor((double)((rel - 1) * A) / D);
+    i64 y = (i64)floor((double)(rel * A) / D);
+    if (x != y) {
+      samp_rank[y] = (u32)r;
+      samp_pos[y] = pos;
+    }
+  }
+};
+
+__global__ void k_emit_all(LeafEmit E) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < E.N) E.emit(r, r);
+}
+
 struct LeafFilterIn {
   const u32 *sa;
   u32 b;
   __device__ __forceinline__ u32 operator()(size_t i) const { return sa[i] < b; }
 };
 struct LeafFilterOut {
-  const u32 *sa;
-  u32 *out;
+  LeafEmit E;
   __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
-    if (in != ex) out[ex] = sa[i];
+    if (in != ex) E.emit(ex, i);
   }
 };
 
@@ -206,13 +280,33 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
   return b;
 }
 
-// Sorts the window [a,e); on success the leaf suffix array (b-a entries) is in *out.
-static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_out) {
+// How many symbols the round-0 key holds.  Every 8 key bits cost one radix pass
+// over the whole window; fewer symbols leave more suffixes tied for the
+// refinement rounds, which only touch the tied ones.  Take the fewest passes for
+// which a random text of this alphabet would leave under 2 % tied.
+static int choose_k0(int w, int max_sym, u64 N) {
+  const int kmax = (64 - w) / w;
+  const double sigma = max_sym < 2 ? 2.0 : (double)max_sym;
+  for (int passes = 1; passes * 8 <= kmax * w + 7; passes++) {
+    int k = passes * 8 / w;
+    if (k > kmax) k = kmax;
+    if (k < 1) continue;
+    double distinct = 1;
+    for (int j = 0; j < k && distinct < 1e30; j++) distinct *= sigma;
+    if ((double)N / distinct <= 0.02) return k;
+  }
+  return kmax;
+}
+
+// Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
+// been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
+static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_out) {
   const u64 N = (u64)(e - a);
   const int w = c.sym_bits;
-  const int K0 = 64 / w;
+  const int K0 = choose_k0(w, c.max_sym, N);
   const int K1 = 32 / w;
   const int low_bit = 64 - K0 * w;
+  const u64 sym_mask = ~0ull << low_bit;
   DBuf<u64> kb0(c, N), kb1(c, N);
   DBuf<u32> sb0(c, N), sb1(c, N);
   u64 *keys[2] = {kb0.get(), kb1.get()};
@@ -243,7 +337,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
   u32 M;
   {
     Phase ph(c, "leaf_group", (double)N * 16);
-    scan_generic<TieHead, TieHeadOp>(c, N, GroupIn{keys[cur], N},
+    scan_generic<TieHead, TieHeadOp>(c, N, GroupIn{keys[cur], N, sym_mask},
                                      FirstListOut{sa, wl_slot, wl_pos, wl_grp, d_total, N});
     M = read_u32(c, d_total);
   }
@@ -253,10 +347,14 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
   while (M > 0) {
-    Phase ph(c, round == 0 ? "leaf_text_round" : "leaf_doubling_round", (double)M * 8 * 32);
+    // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
+    // doubling rounds double it but need the inverse array of the whole window (one random write per
+    // window position).  Sparse ties get a few text rounds first; dense or deep ties go to doubling.
+    const bool text_round = !isa.get() && (round == 0 || (round < 8 && (u64)M * 16 < N));
+    Phase ph(c, text_round ? "leaf_text_round" : "leaf_doubling_round", (double)M * 8 * 32);
     DBuf<u64> ck0(c, M), ck1(c, M);
     DBuf<u32> cp0(c, M), cp1(c, M);
-    if (round == 0) {
+    if (text_round) {
       hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos,
                          wl_grp, M, (u32)h, w, K1, ck0.get(), cp0.get());
     } else {
@@ -278,7 +376,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
     c.sort_tag = "";
     DBuf<u32> ns(c, M), np(c, M), ng(c, M);
     scan_generic<TieHead, TieHeadOp>(
-        c, M, GroupIn{ck[cc], M},
+        c, M, GroupIn{ck[cc], M, ~0ull},
         RefineOut{wl_slot, cp[cc], sa, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
     M = read_u32(c, d_total);
     nl_slot = std::move(ns);
@@ -287,24 +385,36 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, DBuf<u32> *out, i64 *depth_
     wl_slot = nl_slot.get();
     wl_pos = nl_pos.get();
     wl_grp = nl_grp.get();
-    h = (round == 0) ? (u64)(K0 + K1) : 2 * h;
+    h = text_round ? h + (u64)K1 : 2 * h;
     round++;
-    if (round > 1 && read_u32(c, d_overflow)) return false;
+    if (!text_round && read_u32(c, d_overflow)) return false;
     if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
   }
-  *depth_out = (i64)h;
-  if (e == b) {
-    *out = std::move(cur ? sb1 : sb0);
-  } else {
-    Phase ph(c, "leaf_window_filter", (double)N * 8 + (double)(b - a) * 4);
-    DBuf<u32> res(c, (size_t)(b - a));
-    scan_generic<u32, SumU32>(c, N, LeafFilterIn{sa, (u32)b}, LeafFilterOut{sa, res.get()});
-    *out = std::move(res);
+  LeafEmit em;
+  if (E) em = *E;
+  else memset(&em, 0, sizeof(em));
+  DBuf<u32> res;
+  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
+  em.sa_out = sa_out ? res.get() : nullptr;
+  em.keys = keys[cur];
+  em.sa = sa;
+  em.N = N;
+  em.sym_mask = sym_mask;
+  em.prev_mask = (1u << w) - 1;
+  {
+    Phase ph(c, "leaf_emit", (double)N * 12 + (double)(b - a) * 2);
+    if (e == b) {
+      hipLaunchKernelGGL(k_emit_all, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, em);
+      HIP_CHECK(hipGetLastError());
+    } else {
+      scan_generic<u32, SumU32>(c, N, LeafFilterIn{sa, (u32)b}, LeafFilterOut{em});
+    }
   }
+  if (sa_out) *sa_out = std::move(res);
   return true;
 }
 
-DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b) {
+static void run_leaf_sort(Ctx &c, i64 a, i64 b, LeafEmit *E, DBuf<u32> *sa_out) {
   if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
   if (a < 0 || b > c.n || a >= b) fail(BWT_HIP_EINVAL, "bad leaf range [%ld,%ld) for n=%ld", (long)a, (long)b, (long)c.n);
   i64 slack = 0;
@@ -314,13 +424,86 @@ DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b) {
     if (slack > c.n - b) slack = c.n - b;
   }
   for (;;) {
-    DBuf<u32> out;
-    i64 depth = 0;
-    if (sort_window(c, a, b, b + slack, &out, &depth)) return out;
+    if (sort_window(c, a, b, b + slack, E, sa_out)) return;
     if (b + slack >= c.n) fail(BWT_HIP_EINTERNAL, "suffix sort overflowed a window that ends at n");
     slack = slack * 8;
     if (slack > c.n - b) slack = c.n - b;
   }
+}
+
+DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b) {
+  DBuf<u32> out;
+  run_leaf_sort(c, a, b, nullptr, &out);
+  return out;
+}
+
+struct SampFilledIn {
+  const u32 *pos;
+  __device__ __forceinline__ u32 operator()(size_t i) const { return pos[i] != 0xFFFFFFFFu; }
+};
+struct SampCompactOut {
+  const u32 *rank_in, *pos_in;
+  u32 *rank_out, *pos_out;
+  u32 *total;
+  size_t n;
+  __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
+    if (in != ex) {
+      rank_out[ex] = rank_in[i];
+      pos_out[ex] = pos_in[i];
+    }
+    if (i + 1 == n) *total = in;
+  }
+};
+
+// bwt_leaf of the reference (include/bwt.h:615-635)
+Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns_req) {
+  const i64 m = b - a;
+  i64 ns = ns_req < m ? ns_req : m;  // include/bwt.h:607
+  if (m >= 2 && ns < 2) fail(BWT_HIP_EINVAL, "ssa_n_samples must be at least 2 (got %ld)", (long)ns_req);
+  if (m < 1) fail(BWT_HIP_EINVAL, "empty leaf");
+  Block *blk = new Block();
+  try {
+    blk->a = a;
+    blk->b = b;
+    blk->L = DBuf<u8>(c, (size_t)m);
+    DBuf<u32> sr(c, (size_t)ns), sp(c, (size_t)ns);
+    HIP_CHECK(hipMemsetAsync(sr.get(), 0xFF, (size_t)ns * 4, c.stream));
+    HIP_CHECK(hipMemsetAsync(sp.get(), 0xFF, (size_t)ns * 4, c.stream));
+    u32 *special = c.d_scalars + 16;
+    HIP_CHECK(hipMemsetAsync(special, 0xFF, 8, c.stream));
+    LeafEmit E;
+    memset(&E, 0, sizeof(E));
+    E.T = c.T;
+    E.n = (u64)c.n;
+    E.a = (u64)a;
+    E.m = (u64)m;
+    E.ns = ns;
+    E.L = blk->L.get();
+    E.samp_rank = sr.get();
+    E.samp_pos = sp.get();
+    E.special = special;
+    run_leaf_sort(c, a, b, &E, nullptr);
+    blk->samp_rank = DBuf<u32>(c, (size_t)ns);
+    blk->samp_pos = DBuf<u32>(c, (size_t)ns);
+    u32 *d_total = c.d_scalars + 8;
+    scan_generic<u32, SumU32>(c, (size_t)ns, SampFilledIn{sp.get()},
+                              SampCompactOut{sr.get(), sp.get(), blk->samp_rank.get(), blk->samp_pos.get(),
+                                             d_total, (size_t)ns});
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, special, 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 2, d_total, 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 3, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    if (c.h_scalars[0] == 0xFFFFFFFFu || c.h_scalars[1] == 0xFFFFFFFFu)
+      fail(BWT_HIP_EINTERNAL, "leaf [%ld,%ld): suffix array is not a permutation of the range", (long)a, (long)b);
+    blk->s_rank = c.h_scalars[0];
+    blk->e_rank = c.h_scalars[1];
+    blk->n_samp = c.h_scalars[2];
+    blk->e_char = *(u8 *)&c.h_scalars[3];
+  } catch (...) {
+    delete blk;
+    throw;
+  }
+  return blk;
 }
 
 }  // namespace bwtamd

@@ -1,59 +1,88 @@
 // Device view of the wavelet matrix and its rank functions.
 //
-// Layout ("rank block" = one 64-byte line = one HBM transaction per rank):
-//   word 0      number of 1 bits of this level before the block (low 32 bits)
-//   words 1..7  448 bits of the level's bit plane, bit i of the plane at
-//               bit (i % 64) of word 1 + (i % 448) / 64 of block i / 448
-// Each 64-bit plane word is one wavefront ballot of 64 consecutive symbols.
-// Levels are stored one after another, `level_words` words apart.
+// The matrix is 4-ary: every level consumes two bits of the symbol code, so a
+// rank query touches ceil(bits/2) rank blocks instead of `bits` -- one block for
+// DNA, four for bytes.  Symbol codes are c - min_sym (min_sym = smallest symbol
+// of the text besides the terminator), which makes a 4-letter alphabet exactly
+// two bits wide.
 //
-// rank(c, i) needs one rank block per level: the walk of the range start
-// (position 0) through the levels depends on c only and is tabulated
-// (p_end[c]), so only the walk of i touches memory.
+// "Rank block" = one 128-byte line (the L2 line; one memory transaction per level):
+//   4 x u32   occurrences of digit 0,1,2,3 on this level before the block
+//   7 x 16 B  chunk k = { low-bit plane word k, high-bit plane word k }: the two
+//             bits of the digits of positions 64k .. 64k+63 of the block, each
+//             plane word being one wavefront ballot
+// so a block covers 448 positions.  Levels are stored one after another,
+// `level_words` 64-bit words apart.
+//
+// Level l+1 holds the sequence of level l stably partitioned by its digit
+// (all 0s, then 1s, 2s, 3s).  rank(c, i) walks i down the levels:
+//   q <- start[l][d] + (occurrences of d on level l before q),  d = l-th digit of c
+// The walk of the range start (position 0) depends on c only and is tabulated
+// (p_end[c]); occ(c, i) = q_end - p_end[c].
+//
+// One position of L (the rank of the block's first suffix) holds a symbol that
+// does not belong to the block (reference: include/bwt.h:234-236 hides it as 0).
+// Here it is stored with code 0 and taken out again by the caller: occ(c, i)
+// drops by one when code(c) == 0 and the hidden position is below i.
 #pragma once
 
 #include "device_utils.h"
 
 namespace bwtamd {
 
-constexpr u32 WM_BLOCK_BITS = 448;
-constexpr u32 WM_BLOCK_WORDS = 8;
+constexpr u32 WM_BLOCK_POS = 448;   // positions per rank block
+constexpr u32 WM_BLOCK_WORDS = 16;  // 64-bit words per rank block (128 bytes)
+constexpr int WM_MAX_LEVELS = 4;
 
 struct WmView {
   const u64 *planes;
   u64 level_words;
   int levels;
-  u32 max_pos;  // last position that has a rank block (>= the block length)
-  u32 n_zeros[8];
+  u32 min_sym;
+  u32 max_pos;               // last position that has a rank block (>= the block length)
+  u32 hidden;                // position of the foreign symbol
+  u32 start[WM_MAX_LEVELS][4];  // first position of each digit's bucket on the NEXT level
 };
 
-// number of 1 bits in plane[0:pos) of one level
-__device__ __forceinline__ u32 wm_rank1(const u64 *__restrict__ lvl, u32 pos) {
-  u32 blk = pos / WM_BLOCK_BITS;
-  u32 off = pos - blk * WM_BLOCK_BITS;
-  const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lvl + (u64)blk * WM_BLOCK_WORDS);
-  ulonglong2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-  u64 wd[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
-  u32 cnt = (u32)wd[0];
+// occurrences of digit d in level[0:pos)
+__device__ __forceinline__ u32 wm_rank_digit(const u64 *__restrict__ lvl, u32 pos, u32 d) {
+  u32 blk = pos / WM_BLOCK_POS;
+  u32 off = pos - blk * WM_BLOCK_POS;
+  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM_BLOCK_WORDS);
   u32 wi = off >> 6, bi = off & 63;
-  u64 part = (1ull << bi) - 1;
+  uint4 hdr = p[0];
+  uint4 ch[7];
+#pragma unroll
+  for (u32 k = 0; k < 7; k++) ch[k] = (k <= wi) ? p[1 + k] : make_uint4(0, 0, 0, 0);
+  u32 cnt = d == 0 ? hdr.x : (d == 1 ? hdr.y : (d == 2 ? hdr.z : hdr.w));
+  const u64 inv0 = (d & 1) ? 0ull : ~0ull, inv1 = (d & 2) ? 0ull : ~0ull;
+  const u64 part = (1ull << bi) - 1;
 #pragma unroll
   for (u32 k = 0; k < 7; k++) {
+    u64 lo = ((u64)ch[k].y << 32) | ch[k].x, hi = ((u64)ch[k].w << 32) | ch[k].z;
     u64 msk = (k < wi) ? ~0ull : (k == wi ? part : 0ull);
-    cnt += __popcll(wd[1 + k] & msk);
+    cnt += __popcll((lo ^ inv0) & (hi ^ inv1) & msk);
   }
   return cnt;
 }
 
-// position reached by walking index i down all levels along the bits of c
-__device__ __forceinline__ u32 wm_walk(const WmView &wm, u32 c, u32 i) {
+// position reached by walking index i down all levels along the digits of code
+__device__ __forceinline__ u32 wm_walk(const WmView &wm, u32 code, u32 i) {
   u32 q = i;
   for (int l = 0; l < wm.levels; l++) {
     q = q < wm.max_pos ? q : wm.max_pos;  // never read past the planes, whatever the caller passes
-    u32 r1 = wm_rank1(wm.planes + (u64)l * wm.level_words, q);
-    q = ((c >> (wm.levels - 1 - l)) & 1) ? wm.n_zeros[l] + r1 : q - r1;
+    u32 d = (code >> (2 * (wm.levels - 1 - l))) & 3;
+    q = wm.start[l][d] + wm_rank_digit(wm.planes + (u64)l * wm.level_words, q, d);
   }
   return q;
+}
+
+// LF-style count: lf_base[c] + walk, minus the hidden symbol when it was counted.
+// lf_base[c] = C[c] - p_end[c]; the result is C[c] + occ(c, i).
+__device__ __forceinline__ u32 wm_lf(const WmView &wm, const u32 *__restrict__ lf_base, u32 c, u32 i) {
+  u32 code = c - wm.min_sym;
+  u32 k = lf_base[c] + wm_walk(wm, code, i);
+  return k - (u32)(code == 0 && wm.hidden < i);
 }
 
 }  // namespace bwtamd

@@ -1,7 +1,10 @@
 // count_alphabets and the wavelet matrix of a block's L (reference:
 // include/bwt.h:200-250, include/wavelet_matrix.h:198-241,
-// include/succinct_bit_vector.h:193-250), rebuilt for one-transaction ranks.
+// include/succinct_bit_vector.h:193-250), rebuilt 4-ary with one 128-byte rank
+// block per level and query (layout in wavelet.h).
 #include "wavelet.h"
+
+#include <string.h>
 
 #include "internal.h"
 #include "scan_tmpl.h"
@@ -82,167 +85,225 @@ void count_alphabets(Ctx &c, Block &blk) {
 // one level of the matrix
 // ----------------------------------------------------------------------------
 constexpr int WM_THREADS = 256;
-constexpr int WM_ROUNDS = 14;                                   // 4 waves x 14 rounds = 56 plane words
-constexpr int WM_TILE_WORDS = (WM_THREADS / 64) * WM_ROUNDS;    // 56 = 8 rank blocks x 7 words
-constexpr int WM_TILE = WM_TILE_WORDS * 64;                     // 3584 symbols
+constexpr int WM_ROUNDS = 14;                                 // 4 waves x 14 rounds = 56 chunks
+constexpr int WM_TILE_WORDS = (WM_THREADS / 64) * WM_ROUNDS;  // 56 = 8 rank blocks x 7 chunks
+constexpr int WM_TILE = WM_TILE_WORDS * 64;                   // 3584 positions
 
-// Plane words of one tile by wave ballots, and the tile's number of zeros.
-// `hidden` is an index whose symbol reads as 0 (T[a-1], include/bwt.h:234-236).
-__global__ void __launch_bounds__(WM_THREADS)
-    k_wm_plane(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u64 *__restrict__ plane,
-               u32 *__restrict__ tile_zeros) {
-  __shared__ u32 wz[WM_THREADS / 64];
-  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 tile0 = blockIdx.x * WM_TILE;
-  u32 zeros = 0;
-#pragma unroll
-  for (int r = 0; r < WM_ROUNDS; r++) {
-    u32 wi = r * (WM_THREADS / 64) + w;
-    u32 idx = tile0 + wi * 64 + lane;
-    bool valid = idx < m;
-    u32 ch = valid ? cur[idx] : 0u;
-    if (idx == hidden) ch = 0;
-    u64 word = __ballot((ch >> shift) & 1);
-    u64 vmask = __ballot(valid);
-    zeros += __popcll(vmask & ~word);
-    if (lane == 0) plane[((u64)blockIdx.x * 8 + wi / 7) * WM_BLOCK_WORDS + 1 + wi % 7] = word;
-  }
-  if (lane == 0) wz[w] = zeros;
-  __syncthreads();
-  if (tid == 0) tile_zeros[blockIdx.x] = wz[0] + wz[1] + wz[2] + wz[3];
+// The code of position idx on this level.  Level 0 reads L itself (raw symbols;
+// the foreign symbol at `hidden` and anything below min_sym become code 0),
+// deeper levels read the partitioned code arrays.
+__device__ __forceinline__ u32 wm_code(const u8 *__restrict__ cur, u32 idx, u32 m, u32 hidden, u32 min_sym,
+                                      bool raw) {
+  if (idx >= m) return 0;
+  u32 ch = cur[idx];
+  if (!raw) return ch;
+  return (idx == hidden || ch < min_sym) ? 0u : ch - min_sym;
 }
 
-// Stable split of the tile's symbols: zeros to [zoff..), ones to [nz + ooff..).
+// Both bit planes of one tile by wave ballots, and the tile's digit counts.
 __global__ void __launch_bounds__(WM_THREADS)
-    k_wm_split(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, const u32 *__restrict__ tile_zoff,
-               const u32 *__restrict__ d_nz, u8 *__restrict__ next) {
-  __shared__ u32 wzero[WM_TILE_WORDS + 1];  // zeros in each word, then exclusive prefix
-  __shared__ u32 wvalid[WM_TILE_WORDS + 1];
+    k_wm_plane(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u32 min_sym, int raw,
+               u64 *__restrict__ plane, u32 *__restrict__ tile_cnt, u32 tiles) {
+  __shared__ u32 wc[WM_THREADS / 64][4];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 tile0 = blockIdx.x * WM_TILE;
-  u8 sym[WM_ROUNDS];
-  u64 words[WM_ROUNDS];
+  u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
   for (int r = 0; r < WM_ROUNDS; r++) {
     u32 wi = r * (WM_THREADS / 64) + w;
     u32 idx = tile0 + wi * 64 + lane;
-    bool valid = idx < m;
-    u32 ch = valid ? cur[idx] : 0u;
-    if (idx == hidden) ch = 0;
-    sym[r] = (u8)ch;
-    u64 word = __ballot((ch >> shift) & 1);
-    u64 vmask = __ballot(valid);
-    words[r] = word;
+    u32 d = (wm_code(cur, idx, m, hidden, min_sym, raw) >> shift) & 3;
+    u64 b0 = __ballot(d & 1), b1 = __ballot(d >> 1), v = __ballot(idx < m);
+    c0 += __popcll(~b1 & ~b0 & v);
+    c1 += __popcll(~b1 & b0 & v);
+    c2 += __popcll(b1 & ~b0 & v);
+    c3 += __popcll(b1 & b0 & v);
     if (lane == 0) {
-      wzero[wi] = __popcll(vmask & ~word);
-      wvalid[wi] = __popcll(vmask);
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(plane + ((u64)blockIdx.x * 8 + wi / 7) * WM_BLOCK_WORDS + 2 +
+                                                       2 * (wi % 7));
+      *dst = make_ulonglong2(b0, b1);
+    }
+  }
+  if (lane == 0) {
+    wc[w][0] = c0;
+    wc[w][1] = c1;
+    wc[w][2] = c2;
+    wc[w][3] = c3;
+  }
+  __syncthreads();
+  if (tid < 4) tile_cnt[(u64)tid * tiles + blockIdx.x] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+}
+
+// Stable 4-way split of the tile's codes: digit d goes to its bucket, after
+// everything of digit d in earlier tiles (tile_off is the scanned [digit][tile] table).
+__global__ void __launch_bounds__(WM_THREADS)
+    k_wm_split(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u32 min_sym, int raw,
+               const u32 *__restrict__ tile_off, u32 tiles, u8 *__restrict__ next) {
+  __shared__ u32 wcnt[4][WM_TILE_WORDS];  // per word: count of each digit, then exclusive prefix over words
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile0 = blockIdx.x * WM_TILE;
+  u8 code[WM_ROUNDS];
+  u64 lo[WM_ROUNDS], hi[WM_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < WM_ROUNDS; r++) {
+    u32 wi = r * (WM_THREADS / 64) + w;
+    u32 idx = tile0 + wi * 64 + lane;
+    u32 cd = wm_code(cur, idx, m, hidden, min_sym, raw);
+    code[r] = (u8)cd;
+    u32 d = (cd >> shift) & 3;
+    u64 b0 = __ballot(d & 1), b1 = __ballot(d >> 1), v = __ballot(idx < m);
+    lo[r] = b0;
+    hi[r] = b1;
+    if (lane < 4) {
+      u64 sel = ((lane & 1) ? b0 : ~b0) & ((lane & 2) ? b1 : ~b1) & v;
+      wcnt[lane][wi] = __popcll(sel);
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    u32 az = 0, av = 0;
+  if (tid < 4) {
+    u32 run = tile_off[(u64)tid * tiles + blockIdx.x];
     for (int k = 0; k < WM_TILE_WORDS; k++) {
-      u32 z = wzero[k], v = wvalid[k];
-      wzero[k] = az;
-      wvalid[k] = av;
-      az += z;
-      av += v;
+      u32 v = wcnt[tid][k];
+      wcnt[tid][k] = run;
+      run += v;
     }
   }
   __syncthreads();
-  const u32 nz = *d_nz;
-  const u32 zoff = tile_zoff[blockIdx.x];
-  const u32 ooff = tile0 - zoff;  // ones before this tile
 #pragma unroll
   for (int r = 0; r < WM_ROUNDS; r++) {
     u32 wi = r * (WM_THREADS / 64) + w;
     u32 idx = tile0 + wi * 64 + lane;
     if (idx < m) {
-      u64 word = words[r];
-      u32 zb = wzero[wi], ob = wvalid[wi] - wzero[wi];
-      bool bit = (word >> lane) & 1;
-      u32 dst = bit ? nz + ooff + ob + __popcll(word & lanemask_lt())
-                    : zoff + zb + __popcll(~word & lanemask_lt());
-      next[dst] = sym[r];
+      u32 d = ((u32)code[r] >> shift) & 3;
+      u64 sel = ((d & 1) ? lo[r] : ~lo[r]) & ((d & 2) ? hi[r] : ~hi[r]);
+      next[wcnt[d][wi] + __popcll(sel & lanemask_lt())] = code[r];
     }
   }
 }
 
-// rank-block headers: exclusive scan of the blocks' popcounts
-struct BlockOnesIn {
+// rank-block headers: exclusive scan of the blocks' digit counts
+struct U4 {
+  u32 v[4];
+};
+struct SumU4 {
+  __device__ __forceinline__ static U4 identity() { return U4{{0, 0, 0, 0}}; }
+  __device__ __forceinline__ static U4 apply(U4 a, U4 b) {
+    return U4{{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2], a.v[3] + b.v[3]}};
+  }
+};
+struct BlockDigitsIn {
   const u64 *plane;
-  __device__ __forceinline__ u32 operator()(size_t b) const {
-    const u64 *p = plane + b * WM_BLOCK_WORDS;
-    u32 s = 0;
+  __device__ __forceinline__ U4 operator()(size_t b) const {
+    const u64 *p = plane + b * WM_BLOCK_WORDS + 2;
+    U4 s = SumU4::identity();
 #pragma unroll
-    for (int k = 1; k < 8; k++) s += __popcll(p[k]);
+    for (int k = 0; k < 7; k++) {
+      u64 lo = p[2 * k], hi = p[2 * k + 1];
+      s.v[0] += __popcll(~hi & ~lo);
+      s.v[1] += __popcll(~hi & lo);
+      s.v[2] += __popcll(hi & ~lo);
+      s.v[3] += __popcll(hi & lo);
+    }
     return s;
   }
 };
 struct BlockHeaderOut {
   u64 *plane;
-  __device__ __forceinline__ void operator()(size_t b, u32 ex, u32) const { plane[b * WM_BLOCK_WORDS] = ex; }
+  __device__ __forceinline__ void operator()(size_t b, U4 ex, U4) const {
+    u32 *h = reinterpret_cast<u32 *>(plane + b * WM_BLOCK_WORDS);
+    h[0] = ex.v[0];
+    h[1] = ex.v[1];
+    h[2] = ex.v[2];
+    h[3] = ex.v[3];
+  }
 };
 
+// bucket starts of the next level = the scanned table's entries of tile 0
+__global__ void k_wm_starts(const u32 *__restrict__ tile_off, u32 tiles, u32 *__restrict__ starts) {
+  if (threadIdx.x < 4) starts[threadIdx.x] = tile_off[(u64)threadIdx.x * tiles];
+}
+
 // p_end[c]: where the walk of position 0 ends for symbol c; lf_base[c] = C[c] - p_end[c]
-__global__ void k_wm_tables(WmView wm, const u32 *__restrict__ C, u32 *__restrict__ tab) {
+__global__ void k_wm_tables(WmView wm, u32 n_codes, const u32 *__restrict__ C, u32 *__restrict__ tab) {
   u32 c = threadIdx.x;
-  u32 p = (c >> wm.levels) ? 0u : wm_walk(wm, c, 0);
+  u32 p = 0;
+  if (c >= wm.min_sym && c - wm.min_sym < n_codes) p = wm_walk(wm, c - wm.min_sym, 0);
   tab[c] = C[c] - p;
   tab[256 + c] = p;
+}
+
+WmView make_view(const Block &blk) {
+  const WaveletDev &wm = blk.wm;
+  WmView v;
+  memset(&v, 0, sizeof(v));
+  v.planes = wm.planes.get();
+  v.level_words = wm.n_blk * WM_BLOCK_WORDS;
+  v.levels = wm.levels;
+  v.min_sym = wm.min_sym;
+  v.max_pos = (u32)(wm.n_blk * WM_BLOCK_POS - 1);
+  v.hidden = (u32)blk.s_rank;
+  for (int l = 0; l < WM_MAX_LEVELS; l++)
+    for (int d = 0; d < 4; d++) v.start[l][d] = wm.start[l][d];
+  return v;
 }
 
 void build_wavelet(Ctx &c, Block &blk) {
   if (blk.wm.built) return;
   count_alphabets(c, blk);
   const u64 m = (u64)blk.len();
-  const int levels = c.sym_bits;
-  Phase ph(c, "wavelet_build", (double)m * levels * 3.2);
+  // code width: symbols min_sym..max_sym become 0..max_sym-min_sym; two bits per level
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  int bits = 1;
+  while (((c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0) >> bits) != 0) bits++;
+  const int levels = (bits + 1) / 2;
+  Phase ph(c, "wavelet_build", (double)m * levels * 3.3);
   const u32 tiles = (u32)(m / WM_TILE) + 1;
   const u64 n_blk = (u64)tiles * 8;
   WaveletDev &wm = blk.wm;
   wm.levels = levels;
+  wm.min_sym = min_sym;
   wm.n_blk = n_blk;
   wm.planes = DBuf<u64>(c, (size_t)levels * n_blk * WM_BLOCK_WORDS);
-  DBuf<u8> t0(c, m), t1(c, m);
-  DBuf<u32> tz(c, tiles);
-  u32 *d_nz = c.d_scalars + 24;  // one word per level
+  DBuf<u8> t0, t1;
+  if (levels > 1) {
+    t0 = DBuf<u8>(c, m);
+    t1 = DBuf<u8>(c, m);
+  }
+  DBuf<u32> tz(c, (size_t)4 * tiles);
+  u32 *d_starts = c.d_scalars + 24;  // 4 words per level
   const u8 *cur = blk.L.get();
   u8 *bufs[2] = {t0.get(), t1.get()};
-  u32 hidden = (u32)blk.s_rank;
+  const u32 hidden = (u32)blk.s_rank;
   for (int l = 0; l < levels; l++) {
-    int shift = levels - 1 - l;
+    const int shift = 2 * (levels - 1 - l);
+    const int raw = l == 0;
     u64 *plane = wm.planes.get() + (u64)l * n_blk * WM_BLOCK_WORDS;
-    hipLaunchKernelGGL(k_wm_plane, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, plane,
-                       tz.get());
+    hipLaunchKernelGGL(k_wm_plane, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, min_sym, raw,
+                       plane, tz.get(), tiles);
     HIP_CHECK(hipGetLastError());
-    scan_exclusive_u32(c, tz.get(), tz.get(), tiles, d_nz + l);
-    scan_generic<u32, SumU32>(c, (size_t)n_blk, BlockOnesIn{plane}, BlockHeaderOut{plane});
+    scan_exclusive_u32(c, tz.get(), tz.get(), (size_t)4 * tiles, nullptr);
+    hipLaunchKernelGGL(k_wm_starts, dim3(1), dim3(64), 0, c.stream, tz.get(), tiles, d_starts + 4 * l);
+    scan_generic<U4, SumU4>(c, (size_t)n_blk, BlockDigitsIn{plane}, BlockHeaderOut{plane});
     if (l + 1 < levels) {
       u8 *nxt = bufs[l & 1];
-      hipLaunchKernelGGL(k_wm_split, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden,
-                         tz.get(), d_nz + l, nxt);
+      hipLaunchKernelGGL(k_wm_split, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, min_sym,
+                         raw, tz.get(), tiles, nxt);
       HIP_CHECK(hipGetLastError());
       cur = nxt;
-      hidden = 0xFFFFFFFFu;  // the copy already holds the hidden symbol as 0
     }
   }
-  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_nz, sizeof(u32) * levels, hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_starts, sizeof(u32) * 4 * levels, hipMemcpyDeviceToHost, c.stream));
   c.sync();
-  for (int l = 0; l < levels; l++) wm.n_zeros[l] = c.h_scalars[l];
+  for (int l = 0; l < levels; l++)
+    for (int d = 0; d < 4; d++) wm.start[l][d] = c.h_scalars[4 * l + d];
   // LF tables
   u32 hC[256];
   for (int k = 0; k < 256; k++) hC[k] = (u32)blk.C[k];
   DBuf<u32> dC(c, 256);
   HIP_CHECK(hipMemcpyAsync(dC.get(), hC, sizeof(hC), hipMemcpyHostToDevice, c.stream));
   wm.lf_base = DBuf<u32>(c, 512);
-  WmView v;
-  v.planes = wm.planes.get();
-  v.level_words = n_blk * WM_BLOCK_WORDS;
-  v.levels = levels;
-  v.max_pos = (u32)(n_blk * WM_BLOCK_BITS - 1);
-  for (int l = 0; l < 8; l++) v.n_zeros[l] = wm.n_zeros[l];
-  hipLaunchKernelGGL(k_wm_tables, dim3(1), dim3(256), 0, c.stream, v, dC.get(), wm.lf_base.get());
+  hipLaunchKernelGGL(k_wm_tables, dim3(1), dim3(256), 0, c.stream, make_view(blk), 1u << (2 * levels), dC.get(),
+                     wm.lf_base.get());
   HIP_CHECK(hipGetLastError());
   c.sync();  // hC is on the stack
   wm.built = true;
@@ -259,11 +320,10 @@ __global__ void k_rank_batch(WmView wm, const u32 *__restrict__ tab, const u8 *_
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nq) return;
   u32 c = sym[k];
-  u32 q = wm_walk(wm, c, pos[k]);
+  u32 v = wm_lf(wm, tab, c, pos[k]);  // C[c] + occ(c, pos)
   if (!lf) {
-    out[k] = q - tab[256 + c];
+    out[k] = v - (tab[c] + tab[256 + c]);  // minus C[c]
   } else {
-    u32 v = tab[c] + q;
     v += (v >= e_rank && c == e_char);
     out[k] = v;
   }
@@ -271,14 +331,8 @@ __global__ void k_rank_batch(WmView wm, const u32 *__restrict__ tab, const u8 *_
 
 void rank_batch(Ctx &c, Block &blk, const u8 *d_sym, const u32 *d_pos, u32 *d_out, size_t nq, bool lf) {
   build_wavelet(c, blk);
-  WmView v;
-  v.planes = blk.wm.planes.get();
-  v.level_words = blk.wm.n_blk * WM_BLOCK_WORDS;
-  v.levels = blk.wm.levels;
-  v.max_pos = (u32)(blk.wm.n_blk * WM_BLOCK_BITS - 1);
-  for (int l = 0; l < 8; l++) v.n_zeros[l] = blk.wm.n_zeros[l];
-  hipLaunchKernelGGL(k_rank_batch, dim3(ceil_div(nq, 256)), dim3(256), 0, c.stream, v, blk.wm.lf_base.get(), d_sym,
-                     d_pos, d_out, (u32)nq, lf ? 1 : 0, (u32)blk.e_char, (u32)blk.e_rank);
+  hipLaunchKernelGGL(k_rank_batch, dim3(ceil_div(nq, 256)), dim3(256), 0, c.stream, make_view(blk),
+                     blk.wm.lf_base.get(), d_sym, d_pos, d_out, (u32)nq, lf ? 1 : 0, (u32)blk.e_char, (u32)blk.e_rank);
   HIP_CHECK(hipGetLastError());
 }
 
