@@ -13,8 +13,8 @@
 // chain restarts from four times as far.
 //
 // g values are written step-major ([step][chain]) so that a wavefront's 64
-// chains store 64 consecutive words.  The histogram is atomic-free: radix sort
-// of g, run ends scattered into S, inclusive max-scan.
+// chains store 64 consecutive words.  The histogram uses no global atomics: g is
+// radix-sorted on its high bits into buckets, each bucket is counted in LDS.
 #include "wavelet.h"
 
 #include "internal.h"
@@ -126,12 +126,74 @@ __global__ void k_g_text_order(const u32 *__restrict__ g, u64 ra, u64 rb, u32 se
   out[i] = g[(end - 1 - i) * n_chains + c];
 }
 
-// sorted g -> S[v] = 1 + index of the last occurrence of v
-__global__ void k_run_ends(const u32 *__restrict__ s, u32 r, u32 *__restrict__ S) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= r) return;
-  u32 v = s[i];
-  if (i + 1 == r || s[i + 1] != v) S[v] = i + 1;
+// ----------------------------------------------------------------------------
+// histogram + prefix sums of g without global atomics.
+//
+// g is radix-sorted on its HIGH bits only (two 8-bit passes for up to 2^29 left
+// suffixes), which groups it into buckets of 2^low consecutive gap indices
+// (low <= 13).  One workgroup per bucket finds its slice [lo, hi) of the
+// partially sorted array, counts it into 2^low LDS counters private to the
+// workgroup, scans them, and writes S[v] = lo + (inclusive count up to v): every
+// g below the bucket lies before `lo` in the array, so no global scan is needed.
+// ----------------------------------------------------------------------------
+constexpr int GH_THREADS = 256;
+constexpr int GH_LOW_MAX = 13;  // 8192 counters = 32 KB of LDS
+
+// number of entries of keys[0:n) whose (key >> low) is < bucket; all 64 lanes cooperate
+__device__ __forceinline__ u32 wave_bucket_start(const u32 *__restrict__ keys, u32 n, int low, u32 bucket) {
+  u32 lo = 0, hi = n;
+  const u32 lane = lane_id();
+  for (;;) {
+    u32 span = hi - lo;
+    if (span <= 64) {
+      bool t = lane < span && (keys[lo + lane] >> low) < bucket;
+      return lo + (u32)__popcll(__ballot(t));
+    }
+    u32 step = span / 64;
+    u32 i = lo + (lane + 1) * step - 1;
+    bool t = (keys[i] >> low) < bucket;
+    u32 cnt = (u32)__popcll(__ballot(t));
+    u32 nlo = lo + cnt * step;
+    if (cnt < 64) hi = lo + (cnt + 1) * step - 1;
+    lo = nlo;
+  }
+}
+
+__global__ void __launch_bounds__(GH_THREADS)
+    k_bucket_prefix(const u32 *__restrict__ keys, u32 total, int low, u32 m, u32 *__restrict__ S) {
+  __shared__ u32 hist[1 << GH_LOW_MAX];
+  __shared__ u32 bounds[2];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x;
+  const u32 width = 1u << low;
+  const u32 bucket = blockIdx.x;
+  for (u32 i = tid; i < width; i += GH_THREADS) hist[i] = 0;
+  if (tid < 128) {
+    u32 v = wave_bucket_start(keys, total, low, bucket + (tid >> 6));
+    if ((tid & 63) == 0) bounds[tid >> 6] = v;
+  }
+  __syncthreads();
+  const u32 lo = bounds[0], hi = bounds[1];
+  for (u32 i = lo + tid; i < hi; i += GH_THREADS) {
+    u32 g = keys[i];
+    if (g <= m) atomicAdd(&hist[g & (width - 1)], 1u);  // LDS counter; fillers (m+1) are skipped
+  }
+  __syncthreads();
+  // inclusive scan of the counters: each thread owns width/256 consecutive ones
+  const u32 per = (width + GH_THREADS - 1) / GH_THREADS;
+  const u32 j0 = tid * per;
+  u32 mine = 0;
+  for (u32 j = j0; j < j0 + per && j < width; j++) mine += hist[j];
+  u32 all;
+  u32 run = lo + block_scan_incl<OpSum>(mine, scan_s, &all) - mine;
+  for (u32 j = j0; j < j0 + per && j < width; j++) {
+    run += hist[j];
+    hist[j] = run;
+  }
+  __syncthreads();
+  const u64 base = (u64)bucket << low;
+  for (u32 j = tid; j < width; j += GH_THREADS)
+    if (base + j <= m) S[base + j] = hist[j];
 }
 
 static int bits_for(u64 x) {
@@ -196,18 +258,21 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
     HIP_CHECK(hipGetLastError());
   }
   {
-    int bits = bits_for(m + 1);
-    Phase ph(c, "gap_histogram", (double)total * ((bits + 7) / 8) * 12 + (double)(m + 1) * 12);
+    const int bits = bits_for(m + 1);
+    const int low = bits < GH_LOW_MAX ? bits : GH_LOW_MAX;
+    const int passes = (bits - low + 7) / 8;
+    Phase ph(c, "gap_histogram", (double)total * (passes * 12 + 4) + (double)(m + 1) * 4);
     u32 *keys[2] = {g0.get(), g1.get()};
     u32 *vals[2] = {nullptr, nullptr};
     c.sort_tag = "gap:";
-    int cur = radix_sort_u32(c, keys, vals, total, 0, bits, 2);
+    int cur = radix_sort_u32(c, keys, vals, total, low, bits, 2);
     c.sort_tag = "";
     G.S = DBuf<u32>(c, m + 1);
-    HIP_CHECK(hipMemsetAsync(G.S.get(), 0, (m + 1) * 4, c.stream));
-    hipLaunchKernelGGL(k_run_ends, dim3(ceil_div(rn, 256)), dim3(256), 0, c.stream, keys[cur], (u32)rn, G.S.get());
+    const u32 n_buckets = (u32)(((m + 1) + ((u64)1 << low) - 1) >> low);
+    KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 4 + (double)(m + 1) * 4);
+    hipLaunchKernelGGL(k_bucket_prefix, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, keys[cur], (u32)total, low,
+                       (u32)m, G.S.get());
     HIP_CHECK(hipGetLastError());
-    scan_inclusive_max_u32(c, G.S.get(), G.S.get(), m + 1);
   }
   return G;
 }
