@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=None, help="leaves (power of two; default 2 on one GPU, one per GPU on several)")
     ap.add_argument("--ssa_n_samples", type=int, default=0)
     ap.add_argument("--seg", type=int, default=0)
-    ap.add_argument("--cpu_n", type=int, default=10 ** 7, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu_n", type=int, default=3 * 10 ** 7, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-timers", action="store_true")
     args = ap.parse_args()
     args.n_given, args.leaves_given = args.n is not None, args.leaves is not None
@@ -112,6 +112,14 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_rs_scatter<u64,pairs>",
                 "bytes_per_launch": work / calls, "avg_launch_ms": round(ms / calls, 4), "launches": calls}
+    # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE and WRITE_SIZE in
+    # separate rocprofv3 runs, FETCH_SIZE doubled as the gfx950 guide prescribes); only for the workload they were taken on
+    tfile = os.path.join(ROOT, "profiles", "r1_traffic_rs_scatter.json")
+    if roof and os.path.exists(tfile):
+        t = json.load(open(tfile))
+        if t["workload"] == {"n": n, "leaves": args.leaves}:
+            roof["traffic"] = t["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r1_traffic_rs_scatter.json"
     phases = {k: {"ms_per_step": round(v[0] / args.steps, 3), "work_per_step": v[1] / args.steps, "calls": v[2]}
               for k, v in sorted(timers.items(), key=lambda kv: -kv[1][0])}
     out = {
