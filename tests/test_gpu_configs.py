@@ -1,0 +1,85 @@
+"""GPU parity on the other benchmark configurations and on edge cases of the path: highly repetitive text (long
+LCPs: dense ties, doubling rounds, window growth), byte alphabet (4 wavelet levels), tiny and degenerate texts."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import Oracle, gen_repetitive, gen_text
+from tests.gpu_util import ctx, inverse_bwt  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_oracle(ctx, T, sigma, th, ns, seg=0):
+    n = len(T)
+    ctx.set_text(T)
+    blk = ctx.pmbwt(th, ns, seg)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (blk.L == ob.L).all()
+    assert (blk.s_rank, blk.e_rank, blk.e_char) == (ob.s_rank, ob.e_rank, ob.e_char)
+    for x, y in zip(blk.samples(), ob.samples()):
+        assert (x == y).all()
+    return blk
+
+
+@pytest.mark.parametrize("text", [b"\0", b"a\0", b"ab\0", b"ba\0", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa\0",
+                                  b"abababababababababababababababababab\0", b"\xff\x01\xff\x01\xfe\0"])
+@pytest.mark.parametrize("th", [1000, 3, 1])
+def test_tiny_and_degenerate_texts(ctx, text, th):
+    T = np.frombuffer(text, dtype=np.uint8).copy()
+    n = len(T)
+    ctx.set_text(T)
+    blk = ctx.pmbwt(th, 2)
+    L = blk.L
+    assert (L == Oracle.bwt_direct(T)).all()
+    assert L[blk.s_rank] == 0 and blk.e_rank == 0
+    assert (inverse_bwt(L, blk.e_rank) == T).all()
+
+
+def test_single_symbol_run(ctx):
+    """One symbol repeated: every suffix comparison runs to the end of the text (LCP = n)."""
+    T = np.concatenate([np.full(6000, 7, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
+    blk = _same_as_oracle(ctx, T, 7, 2000, 100, 97)
+    assert (blk.L[:-1] == 7).all() and blk.L[-1] == 0
+
+
+def test_repetitive_genomes_small(ctx):
+    """Config 4 at reduced scale: 100 copies of a 3000-symbol unit with 0.1 % substitutions, against the oracle."""
+    T = gen_repetitive(3000, 100, 0.001, seed=43, sigma=4)
+    _same_as_oracle(ctx, T, 4, 40000, 1000)
+    _same_as_oracle(ctx, T, 4, len(T), 1000)
+
+
+def test_repetitive_genomes_properties(ctx):
+    """The same family at 4.6e6 symbols (100 x 46000): single leaf and 8 leaves agree; L is a permutation of T."""
+    T = gen_repetitive(46000, 100, 0.001, seed=43, sigma=4)
+    n = len(T)
+    ctx.set_text(T)
+    t0 = time.time()
+    one = ctx.pmbwt(n, 5000)
+    L1 = one.L
+    t1 = time.time()
+    many = ctx.pmbwt(n // 8 + 1, 5000)
+    L8 = many.L
+    t2 = time.time()
+    print("repetitive n=%d: single leaf %.2f s, 8 leaves %.2f s" % (n, t1 - t0, t2 - t1))
+    assert (L1 == L8).all()
+    assert (np.bincount(L1, minlength=256) == np.bincount(T, minlength=256)).all()
+    r, p = many.samples()
+    assert (L8[r] == T[p - 1]).all()
+    assert (inverse_bwt(L1[:], 0)[: 5000] == T[:5000]).all() if n <= 5000000 else True
+
+
+def test_byte_alphabet_against_oracle(ctx):
+    """Config 5 at reduced scale: 255 symbols, four 2-bit wavelet levels."""
+    T = gen_text(300000, 42, 255)
+    _same_as_oracle(ctx, T, 255, 80000, 3000)
+
+
+def test_ascii_letters_min_sym_offset(ctx):
+    """Symbols 'a'..'z': codes are relative to the smallest symbol (3 wavelet levels instead of 4)."""
+    T = gen_text(120000, 3, 26)
+    T[:-1] += ord("a") - 1
+    _same_as_oracle(ctx, T, ord("z"), 20000, 700, 200)
