@@ -82,17 +82,24 @@ __device__ __forceinline__ u32 block_scan_incl(u32 v, u32 *smem, u32 *block_tota
   return Op::apply(carry, incl);
 }
 
-// Which lanes of the wave hold the same 8-bit digit as this lane, among the
-// lanes flagged valid.  Eight ballots: one per digit bit.
-__device__ __forceinline__ u64 match_digit8(u32 digit, bool valid) {
-  u64 m = __ballot(valid);
+// Which lanes of the wave hold the same 8-bit digit as this lane.  lo/hi come in
+// as the two halves of the mask of participating lanes and go out as the mask of
+// this lane's peers (itself included).  One ballot per digit bit; per bit and
+// half the update  m &= ~(ballot ^ my_bit_replicated)  is a single three-input
+// bit operation on gfx950.
+__device__ __forceinline__ void match_digit8(u32 digit, u32 &lo, u32 &hi) {
 #pragma unroll
   for (int b = 0; b < 8; b++) {
-    bool bit = (digit >> b) & 1;
-    u64 bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
+    const int32_t bm = __builtin_amdgcn_sbfe((int32_t)digit, b, 1);  // all ones if bit b is set
+    const u64 bal = __ballot(bm < 0);
+    lo = __builtin_amdgcn_bitop3_b32(lo, (u32)bal, (u32)bm, 0x90);  // lo & ~(bal ^ bm)
+    hi = __builtin_amdgcn_bitop3_b32(hi, (u32)(bal >> 32), (u32)bm, 0x90);
   }
-  return m;
+}
+
+// number of set bits of (hi:lo) below this lane
+__device__ __forceinline__ u32 count_below_lane(u32 lo, u32 hi) {
+  return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
 }
 
 }  // namespace bwtamd

@@ -162,7 +162,16 @@ void scan_inclusive_max_u32(Ctx &c, const u32 *in, u32 *out, size_t n);
 // vals may be {nullptr,nullptr} for keys only.  Returns which pair (0 or 1)
 // holds the result.  n < 2^32.  `use` picks a kernel instantiation named after
 // the caller (0 leaf sort, 1 refinement rounds and tests, 2 gap histogram).
-int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
+// Keys that are a function of the text: key(i) = K0 symbols from position a+i (w bits each, left-aligned)
+// with the symbol before a+i in the low w bits, value(i) = a+i.
+struct TextKeys {
+  const u8 *T;
+  u64 n, a;
+  int w, K0;
+};
+// With `text`, the first pass takes keys and values from it instead of keys[0]/vals[0] (use 0 only).
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1,
+                   const TextKeys *text = nullptr);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------
@@ -171,7 +180,7 @@ int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 struct WaveletDev {
   int levels = 0;        // two code bits per level
   u32 min_sym = 1;       // code = symbol - min_sym
-  u64 n_blk = 0;         // 128-byte rank blocks per level
+  u64 n_blk = 0;         // rank blocks per level
   DBuf<u64> planes;      // levels * n_blk * 16 words
   u32 start[4][4] = {};  // per level: first position of each digit's bucket on the next level
   DBuf<u32> lf_base;     // 512 entries: C[c] - p_end[c], then p_end[c]

@@ -13,6 +13,14 @@
 // bumps the wave's private LDS counter, so equal digits keep their input order
 // (the sort is stable, which LSD needs).  The histogram kernel only counts, so
 // it uses LDS atomic adds on per-wave counter rows.
+//
+// The first pass of the leaf suffix sort does not read a key array at all: its
+// keys are a function of the text (TextKeys in internal.h), so the histogram and
+// scatter kernels of that pass stage the tile's stretch of text in LDS and roll
+// the keys out of it.  That removes the key-building pass (13 bytes written and
+// 20 read back per suffix) from the leaf sort.
+#include <string.h>
+
 #include "device_utils.h"
 #include "internal.h"
 
@@ -35,16 +43,100 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+
+// ----------------------------------------------------------------------------
+// keys rolled out of the text (first pass of the leaf suffix sort)
+//   key(i) = | K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
+//              left-aligned | zero padding | T[a+i-1] in the low w bits |
+//   value(i) = a + i
+// Positions >= n read as 0; T[-1] is T[n-1].
+// ----------------------------------------------------------------------------
+constexpr int TK_LEAD = 4;  // staged bytes in front of the tile's first symbol (the preceding symbol is the last of them)
+constexpr int TK_STAGE_WORDS = (TK_LEAD + RS_TILE + 64 + 4 + 3) / 4 + 1;
+
+// S[k] = symbol at text position a + tile0 - TK_LEAD + k, for every k a key of the tile can touch
+__device__ __forceinline__ void tk_stage(u32 *S32, const TextKeys &tk, u64 tile0, u32 tid, u32 nthreads) {
+  const i64 p0 = (i64)(tk.a + tile0) - TK_LEAD;
+  const u32 words = (u32)(TK_LEAD + RS_TILE + tk.K0 + 4 + 3) / 4;
+  if (p0 >= 0 && (u64)p0 + (u64)words * 4 + 8 <= tk.n) {
+    // aligned dword loads, shifted to the tile's own alignment
+    const uintptr_t ad = reinterpret_cast<uintptr_t>(tk.T + p0);
+    const u32 off = (u32)(ad & 3);
+    const u32 *G = reinterpret_cast<const u32 *>(ad - off);
+    for (u32 q = tid; q < words; q += nthreads) {
+      u64 two = ((u64)G[q + 1] << 32) | G[q];
+      S32[q] = (u32)(two >> (8 * off));
+    }
+  } else {
+    u8 *S = reinterpret_cast<u8 *>(S32);
+    for (u32 k = tid; k < words * 4; k += nthreads) {
+      i64 p = p0 + (i64)k;
+      u8 ch = 0;
+      if (p == -1) ch = tk.T[tk.n - 1];
+      else if (p >= 0 && (u64)p < tk.n) ch = tk.T[p];
+      S[k] = ch;
+    }
+  }
+}
+
+// keys k0 .. k0+ITEMS-1 of the tile (k0 a multiple of 4), from the staged text
+template <int ITEMS>
+__device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
+  const int w = tk.w, K0 = tk.K0;
+  const int used = K0 * w;  // <= 64 - w
+  const u64 maskall = (1ull << used) - 1;
+  const int lsh = 64 - used;
+  const u32 symmask = (1u << w) - 1;
+  const u32 *src = S32 + (TK_LEAD + k0) / 4;
+  u64 sf = 0;
+  u32 wd = 0;
+  for (int k = 0; k < K0; k++) {
+    if ((k & 3) == 0) wd = src[k >> 2];
+    sf = (sf << w) | (wd & 255u);
+    wd >>= 8;
+  }
+  u32 prev = reinterpret_cast<const u8 *>(S32)[TK_LEAD + k0 - 1];
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    key_out[j] = (sf << lsh) | prev;
+    prev = (u32)(sf >> (used - w)) & symmask;
+    const int k = K0 + j;
+    if ((k & 3) == 0) wd = src[k >> 2];
+    sf = ((sf << w) | (wd & 255u)) & maskall;
+    wd >>= 8;
+  }
+}
+
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
 // rounds, 2 gap histogram), so that a profiler lists their launches apart.
-template <class K, int USE>
+template <class K, int USE, bool TEXT>
 __global__ void __launch_bounds__(RH_THREADS)
-    k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk) {
+    k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk,
+              TextKeys tk) {
   __shared__ u32 cnt[RH_THREADS / 64][256];  // one row of LDS counters per wave
+  __shared__ u32 stage[TEXT ? TK_STAGE_WORDS : 1];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
   const u32 tile = xcd_tile(blockIdx.x, nblk);
   const size_t tile0 = (size_t)tile * RS_TILE;
+  if constexpr (TEXT) {
+    // thread t counts keys 16t .. 16t+15 of the tile
+    tk_stage(stage, tk, tile0, tid, RH_THREADS);
+    __syncthreads();
+    u64 key[RH_ITEMS];
+    tk_roll<RH_ITEMS>(stage, tid * RH_ITEMS, tk, key);
+#pragma unroll
+    for (int r = 0; r < RH_ITEMS; r++) {
+      u32 d = (u32)(key[r] >> shift) & mask;
+      if (tile0 + tid * RH_ITEMS + r < n) atomicAdd(&cnt[w][d], 1u);
+    }
+    __syncthreads();
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
+    counts[(size_t)tid * nblk + tile] = tot;
+    return;
+  }
   K key[RH_ITEMS];
   const bool full = tile0 + RS_TILE <= n;
   if (full) {  // all loads issued before the first use: 16 bytes per lane and load
@@ -84,53 +176,48 @@ __global__ void __launch_bounds__(RH_THREADS)
   counts[(size_t)tid * nblk + tile] = tot;
 }
 
-template <class K, bool HAS_VALS, int USE>
-__global__ void __launch_bounds__(RS_THREADS)
-    k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
-                 u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
-                 u32 nblk) {
-  // One LDS buffer, used twice: first the per-wave digit counters and the digit
-  // starts, then (after every thread has turned its ranks into tile positions)
-  // the tile's keys and values in digit order.
-  constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
-  constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
-  constexpr size_t BUF_BYTES = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
-  __shared__ __align__(16) unsigned char buf[BUF_BYTES];
-  __shared__ u32 gbase[256];
-  __shared__ u32 scan_s[17];
+template <class K>
+__device__ __forceinline__ u32 digit_of(K key, int shift, u32 mask) {
+  return (u32)(key >> shift) & mask;
+}
+
+// Ranking, ordering in LDS and writing of one tile.  FULL: the tile has all RS_TILE keys.
+template <class K, bool HAS_VALS, bool FULL>
+__device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
+                                                u32 *gbase, u32 *scan_s, K *__restrict__ kout,
+                                                u32 *__restrict__ vout, u32 tile_n, int shift, u32 mask,
+                                                const u32 *__restrict__ offs, u32 nblk, u32 tile) {
   u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * 256;
   K *keys_s = reinterpret_cast<K *>(buf);
   u32 *vals_s = reinterpret_cast<u32 *>(buf + RS_TILE * sizeof(K));
-
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 tile = xcd_tile(blockIdx.x, nblk);
-  const size_t tile0 = (size_t)tile * RS_TILE;
-  const u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
-  for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
-
-  K key[RS_ITEMS];
-  u32 val[RS_ITEMS];
-  u32 rk[RS_ITEMS];
   const u32 wbase = w * RS_PER_WAVE;
+  u32 *myc = cnt[w];  // this wave's counters: no other wave touches them before the barrier
+  for (u32 d = lane; d < 256; d += 64) myc[d] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+  u32 dig[RS_ITEMS], rk[RS_ITEMS];
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    u32 idx = wbase + r * 64 + lane;
-    bool valid = idx < tile_n;
-    key[r] = valid ? kin[tile0 + idx] : (K)0;
-    if (HAS_VALS) val[r] = valid ? vin[tile0 + idx] : 0u;
-  }
-  volatile u32 *myc = cnt[w];
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    u32 idx = wbase + r * 64 + lane;
-    bool valid = idx < tile_n;
-    u32 d = (u32)(key[r] >> shift) & mask;
-    u64 peers = match_digit8(d, valid);
-    u32 before = __popcll(peers & lanemask_lt());
-    u32 base = valid ? myc[d] : 0u;
+    const bool valid = FULL || (wbase + r * 64 + lane < tile_n);
+    const u32 d = digit_of<K>(key[r], shift, mask);
+    dig[r] = d;
+    u32 lo = ~0u, hi = ~0u;
+    if (!FULL) {
+      u64 v = __ballot(valid);
+      lo = (u32)v;
+      hi = (u32)(v >> 32);
+    }
+    match_digit8(d, lo, hi);
+    const u32 before = count_below_lane(lo, hi);
+    // The wave's LDS operations execute in program order: every peer reads the counter, then the
+    // first peer adds the group's size; the next 64 keys see the sum.
+    const u32 base = __hip_atomic_load(&myc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (valid && before == 0)
+      __hip_atomic_fetch_add(&myc[d], (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     rk[r] = base + before;
-    if (valid && before == 0) myc[d] = base + __popcll(peers);
   }
   __syncthreads();
   {
@@ -154,45 +241,143 @@ __global__ void __launch_bounds__(RS_THREADS)
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    u32 d = (u32)(key[r] >> shift) & mask;
-    rk[r] += dstart[d] + cnt[w][d];  // position inside the tile
-  }
+  for (int r = 0; r < RS_ITEMS; r++) rk[r] += dstart[dig[r]] + myc[dig[r]];  // position inside the tile
   __syncthreads();  // counters are dead from here: the buffer becomes the staging area
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    u32 idx = wbase + r * 64 + lane;
-    if (idx < tile_n) {
+    if (FULL || wbase + r * 64 + lane < tile_n) {
       keys_s[rk[r]] = key[r];
       if (HAS_VALS) vals_s[rk[r]] = val[r];
     }
   }
   __syncthreads();
-  for (u32 p = tid; p < tile_n; p += RS_THREADS) {
-    K k = keys_s[p];
-    u32 d = (u32)(k >> shift) & mask;
-    u32 dst = gbase[d] + p;
-    kout[dst] = k;
-    if (HAS_VALS) vout[dst] = vals_s[p];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const u32 p = r * RS_THREADS + tid;
+    if (FULL || p < tile_n) {
+      K k = keys_s[p];
+      u32 dst = gbase[digit_of<K>(k, shift, mask)] + p;
+      kout[dst] = k;
+      if (HAS_VALS) vout[dst] = vals_s[p];
+    }
   }
 }
 
+template <class K, bool HAS_VALS, int USE, bool TEXT>
+__global__ void __launch_bounds__(RS_THREADS, 6)
+    k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
+                 u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
+                 u32 nblk, TextKeys tk) {
+  // One LDS buffer, used twice: first the per-wave digit counters and the digit
+  // starts, then (after every thread has turned its ranks into tile positions)
+  // the tile's keys and values in digit order.
+  constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
+  constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
+  constexpr size_t BUF_BYTES = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
+  __shared__ __align__(16) unsigned char buf[BUF_BYTES];
+  __shared__ u32 gbase[256];
+  __shared__ u32 scan_s[17];
+
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile = xcd_tile(blockIdx.x, nblk);
+  const size_t tile0 = (size_t)tile * RS_TILE;
+  const u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
+  const bool full = tile_n == RS_TILE;
+
+  K key[RS_ITEMS];
+  u32 val[RS_ITEMS];
+  const u32 wbase = w * RS_PER_WAVE;
+  if constexpr (TEXT) {
+    // The same buffer first holds the staged text (behind the key exchange area) and the keys that
+    // thread t rolled for tile indices 8t .. 8t+7, 9 words apart per thread against bank conflicts;
+    // every thread then picks up the keys of its ranking slots.
+    static_assert(sizeof(K) == 8 && HAS_VALS, "text keys are 64-bit and carry their position");
+    constexpr u32 EX_WORDS = RS_THREADS * (RS_ITEMS + 1);
+    static_assert(EX_WORDS * 8 + TK_STAGE_WORDS * 4 <= BUF_BYTES, "exchange area and staged text share the buffer");
+    K *ex = reinterpret_cast<K *>(buf);
+    u32 *stage = reinterpret_cast<u32 *>(buf + EX_WORDS * 8);
+    tk_stage(stage, tk, tile0, tid, RS_THREADS);
+    __syncthreads();
+    u64 mine[RS_ITEMS];
+    tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; j++) ex[tid * (RS_ITEMS + 1) + j] = mine[j];
+    __syncthreads();
+    const u32 pos0 = (u32)(tk.a + tile0);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+      u32 idx = wbase + r * 64 + lane;
+      bool valid = idx < tile_n;
+      key[r] = valid ? ex[(idx / RS_ITEMS) * (RS_ITEMS + 1) + (idx % RS_ITEMS)] : (K)0;
+      val[r] = pos0 + idx;
+    }
+    __syncthreads();  // the exchange area becomes the counters
+  } else {
+    const K *kt = kin + tile0;      // uniform base + 32-bit lane offset
+    const u32 *vt = vin + tile0;
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < RS_ITEMS; r++) {
+        u32 idx = wbase + r * 64 + lane;
+        key[r] = kt[idx];
+        if (HAS_VALS) val[r] = vt[idx];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RS_ITEMS; r++) {
+        u32 idx = wbase + r * 64 + lane;
+        bool valid = idx < tile_n;
+        key[r] = valid ? kt[idx] : (K)0;
+        if (HAS_VALS) val[r] = valid ? vt[idx] : 0u;
+      }
+    }
+  }
+  if (full)
+    rs_scatter_tile<K, HAS_VALS, true>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk, tile);
+  else
+    rs_scatter_tile<K, HAS_VALS, false>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk, tile);
+}
+
 template <class K, int USE>
-static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
+static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit,
+                           const TextKeys *text = nullptr) {
   if (n == 0 || end_bit <= begin_bit) return 0;
   if (n >= (1ull << 32)) fail(BWT_HIP_EINVAL, "radix sort: %zu elements exceed 2^32-1", n);
   u32 nblk = ceil_div(n, RS_TILE);
   DBuf<u32> counts(c, (size_t)256 * nblk);
   const bool has_vals = vals[0] != nullptr;
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
   int cur = 0;
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     u32 mask = (1u << bits) - 1;
+    if constexpr (sizeof(K) == 8 && USE == 0) {
+      if (text && shift == begin_bit) {  // keys and positions of this pass come out of the text
+        if (!has_vals) fail(BWT_HIP_EINTERNAL, "text keys need a value array");
+        {
+          KernelTimer kt(c, (std::string(c.sort_tag) + "k_rs_hist_text").c_str(), (double)n);
+          hipLaunchKernelGGL((k_rs_hist<K, USE, true>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const K *)nullptr,
+                             n, shift, mask, counts.get(), nblk, *text);
+          HIP_CHECK(hipGetLastError());
+        }
+        scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+        {
+          KernelTimer kt(c, (std::string(c.sort_tag) + "k_rs_scatter_text").c_str(), (double)n * 13);
+          hipLaunchKernelGGL((k_rs_scatter<K, true, USE, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                             (const K *)nullptr, (const u32 *)nullptr, keys[cur ^ 1], vals[cur ^ 1], n, shift, mask,
+                             counts.get(), nblk, *text);
+          HIP_CHECK(hipGetLastError());
+        }
+        cur ^= 1;
+        continue;
+      }
+    }
     {
       KernelTimer kt(c, (std::string(c.sort_tag) + (sizeof(K) == 8 ? "k_rs_hist_u64" : "k_rs_hist_u32")).c_str(),
                      (double)n * sizeof(K));
-      hipLaunchKernelGGL((k_rs_hist<K, USE>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, keys[cur], n, shift, mask,
-                         counts.get(), nblk);
+      hipLaunchKernelGGL((k_rs_hist<K, USE, false>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, keys[cur], n, shift,
+                         mask, counts.get(), nblk, none);
       HIP_CHECK(hipGetLastError());
     }
     scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
@@ -201,12 +386,12 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
                                       : (has_vals ? "k_rs_scatter_u32_pairs" : "k_rs_scatter_u32_keys");
       KernelTimer kt(c, (std::string(c.sort_tag) + nm).c_str(), (double)n * 2 * (sizeof(K) + (has_vals ? 4 : 0)));
       if (has_vals)
-        hipLaunchKernelGGL((k_rs_scatter<K, true, USE>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
-                           vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk);
+        hipLaunchKernelGGL((k_rs_scatter<K, true, USE, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+                           vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk, none);
       else
-        hipLaunchKernelGGL((k_rs_scatter<K, false, USE>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
+        hipLaunchKernelGGL((k_rs_scatter<K, false, USE, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream, keys[cur],
                            (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(),
-                           nblk);
+                           nblk, none);
       HIP_CHECK(hipGetLastError());
     }
     cur ^= 1;
@@ -214,8 +399,10 @@ static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin
   return cur;
 }
 
-int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use) {
-  if (use == 0) return radix_sort_impl<u64, 0>(c, keys, vals, n, begin_bit, end_bit);
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use,
+                   const TextKeys *text) {
+  if (use == 0) return radix_sort_impl<u64, 0>(c, keys, vals, n, begin_bit, end_bit, text);
+  if (text) fail(BWT_HIP_EINTERNAL, "text keys belong to the leaf sort");
   return radix_sort_impl<u64, 1>(c, keys, vals, n, begin_bit, end_bit);
 }
 

@@ -2,8 +2,11 @@
 // suffixes (what the reference's idx_less comparison sort produces,
 // include/suffix_array.h:14-49), by radix sort + prefix doubling.
 //
-//   round 0   key = first K0 symbols packed into 64 bits; LSD radix sort of
-//             (key, position) over the window [a, e), e = b + slack
+//   round 0   key = first K0 symbols packed into 64 bits (plus the preceding
+//             symbol in the low bits, which is not sorted on and later yields the
+//             BWT symbol without a read of the text); LSD radix sort of
+//             (key, position) over the window [a, e), e = b + slack; the first
+//             pass computes the keys from the text on the fly
 //   tie list  suffixes whose key is shared form groups; only those stay active
 //   text rnd  active suffixes are ordered inside their group by the next K1
 //             symbols read from the text (no inverse array needed; on random
@@ -26,59 +29,6 @@
 #include "scan_tmpl.h"
 
 namespace bwtamd {
-
-// ----------------------------------------------------------------------------
-// round 0 keys
-// ----------------------------------------------------------------------------
-constexpr int KB_THREADS = 256;
-constexpr int KB_ITEMS = 16;
-constexpr int KB_TILE = KB_THREADS * KB_ITEMS;
-
-// keys[i] = | K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
-//             left-aligned | zero padding | T[a+i-1] in the low w bits |
-// Positions >= n read as 0; T[-1] is T[n-1].  Only the symbol field is sorted
-// on; the preceding symbol rides along so that the BWT symbol of every suffix
-// that round 0 already places comes out of the sorted key, not out of a random
-// read of the text.  sa[i] = a + i.
-// Each thread rolls 16 consecutive keys; they go through LDS so that the global
-// stores are contiguous per wave.
-__global__ void __launch_bounds__(KB_THREADS)
-    k_build_keys(const u8 *__restrict__ T, u64 n, u64 a, u64 N, int w, int K0, u64 *__restrict__ keys,
-                 u32 *__restrict__ sa) {
-  __shared__ u8 s[KB_TILE + 72];        // s[k] = T[a + tile0 - 1 + k]
-  __shared__ u64 ks[KB_THREADS * 17];   // 16 keys per thread, padded to 17 against bank conflicts
-  const u32 tid = threadIdx.x;
-  const u64 tile0 = (u64)blockIdx.x * KB_TILE;
-  for (u32 i = tid; i < KB_TILE + 72; i += KB_THREADS) {
-    u64 p = a + tile0 + i;  // text position + 1
-    u8 ch = 0;
-    if (p == 0) ch = T[n - 1];
-    else if (p - 1 < n) ch = T[p - 1];
-    s[i] = ch;
-  }
-  __syncthreads();
-  const u32 t0 = tid * KB_ITEMS;
-  const int used = K0 * w;
-  const u64 maskall = (1ull << used) - 1;  // used <= 64 - w < 64
-  const int lsh = 64 - used;
-  u64 key = 0;
-  for (int k = 0; k < K0; k++) key = (key << w) | s[1 + t0 + k];
-#pragma unroll
-  for (int j = 0; j < KB_ITEMS; j++) {
-    ks[tid * 17 + j] = (key << lsh) | s[t0 + j];
-    key = ((key << w) | s[1 + t0 + j + K0]) & maskall;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < KB_ITEMS; r++) {
-    u32 e = r * KB_THREADS + tid;
-    u64 idx = tile0 + e;
-    if (idx < N) {
-      keys[idx] = ks[(e >> 4) * 17 + (e & 15)];
-      sa[idx] = (u32)(a + idx);
-    }
-  }
-}
 
 // ----------------------------------------------------------------------------
 // grouping scan: counts ties and carries the last group head
@@ -311,18 +261,14 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   DBuf<u32> sb0(c, N), sb1(c, N);
   u64 *keys[2] = {kb0.get(), kb1.get()};
   u32 *vals[2] = {sb0.get(), sb1.get()};
-  {
-    Phase ph(c, "leaf_key_build", (double)N * 13);
-    hipLaunchKernelGGL(k_build_keys, dim3(ceil_div(N, KB_TILE)), dim3(KB_THREADS), 0, c.stream, c.T, (u64)c.n,
-                       (u64)a, N, w, K0, keys[0], vals[0]);
-    HIP_CHECK(hipGetLastError());
-  }
   int cur;
   {
+    // round 0: the first pass rolls its keys (symbols | preceding symbol) out of the text
     int passes = (64 - low_bit + 7) / 8;
-    Phase ph(c, "leaf_radix_sort", (double)N * passes * 32);
+    Phase ph(c, "leaf_radix_sort", (double)N * (passes * 32 - 19));
+    TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0};
     c.sort_tag = "leaf:";
-    cur = radix_sort_u64(c, keys, vals, N, low_bit, 64, 0);
+    cur = radix_sort_u64(c, keys, vals, N, low_bit, 64, 0, &tk);
     c.sort_tag = "";
   }
   u32 *sa = vals[cur];

@@ -6,13 +6,14 @@
 // of the text besides the terminator), which makes a 4-letter alphabet exactly
 // two bits wide.
 //
-// "Rank block" = one 128-byte line (the L2 line; one memory transaction per level):
+// "Rank block" = one aligned 64-byte sector (what the memory side fetches for a
+// random access; a query touches exactly one per level):
 //   4 x u32   occurrences of digit 0,1,2,3 on this level before the block
-//   7 x 16 B  chunk k = { low-bit plane word k, high-bit plane word k }: the two
+//   3 x 16 B  chunk k = { low-bit plane word k, high-bit plane word k }: the two
 //             bits of the digits of positions 64k .. 64k+63 of the block, each
 //             plane word being one wavefront ballot
-// so a block covers 448 positions.  Levels are stored one after another,
-// `level_words` 64-bit words apart.
+// so a block covers 192 positions (1/3 byte per position and level).  Levels are
+// stored one after another, `level_words` 64-bit words apart.
 //
 // Level l+1 holds the sequence of level l stably partitioned by its digit
 // (all 0s, then 1s, 2s, 3s).  rank(c, i) walks i down the levels:
@@ -30,8 +31,9 @@
 
 namespace bwtamd {
 
-constexpr u32 WM_BLOCK_POS = 448;   // positions per rank block
-constexpr u32 WM_BLOCK_WORDS = 16;  // 64-bit words per rank block (128 bytes)
+constexpr u32 WM_CHUNKS = 3;                       // 64-position chunks per rank block
+constexpr u32 WM_BLOCK_POS = 64 * WM_CHUNKS;       // positions per rank block
+constexpr u32 WM_BLOCK_WORDS = 2 + 2 * WM_CHUNKS;  // 64-bit words per rank block (64 bytes)
 constexpr int WM_MAX_LEVELS = 4;
 
 struct WmView {
@@ -51,14 +53,14 @@ __device__ __forceinline__ u32 wm_rank_digit(const u64 *__restrict__ lvl, u32 po
   const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM_BLOCK_WORDS);
   u32 wi = off >> 6, bi = off & 63;
   uint4 hdr = p[0];
-  uint4 ch[7];
+  uint4 ch[WM_CHUNKS];
 #pragma unroll
-  for (u32 k = 0; k < 7; k++) ch[k] = (k <= wi) ? p[1 + k] : make_uint4(0, 0, 0, 0);
+  for (u32 k = 0; k < WM_CHUNKS; k++) ch[k] = (k <= wi) ? p[1 + k] : make_uint4(0, 0, 0, 0);
   u32 cnt = d == 0 ? hdr.x : (d == 1 ? hdr.y : (d == 2 ? hdr.z : hdr.w));
   const u64 inv0 = (d & 1) ? 0ull : ~0ull, inv1 = (d & 2) ? 0ull : ~0ull;
   const u64 part = (1ull << bi) - 1;
 #pragma unroll
-  for (u32 k = 0; k < 7; k++) {
+  for (u32 k = 0; k < WM_CHUNKS; k++) {
     u64 lo = ((u64)ch[k].y << 32) | ch[k].x, hi = ((u64)ch[k].w << 32) | ch[k].z;
     u64 msk = (k < wi) ? ~0ull : (k == wi ? part : 0ull);
     cnt += __popcll((lo ^ inv0) & (hi ^ inv1) & msk);

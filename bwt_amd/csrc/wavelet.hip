@@ -1,6 +1,6 @@
 // count_alphabets and the wavelet matrix of a block's L (reference:
 // include/bwt.h:200-250, include/wavelet_matrix.h:198-241,
-// include/succinct_bit_vector.h:193-250), rebuilt 4-ary with one 128-byte rank
+// include/succinct_bit_vector.h:193-250), rebuilt 4-ary with one 64-byte rank
 // block per level and query (layout in wavelet.h).
 #include "wavelet.h"
 
@@ -85,9 +85,11 @@ void count_alphabets(Ctx &c, Block &blk) {
 // one level of the matrix
 // ----------------------------------------------------------------------------
 constexpr int WM_THREADS = 256;
-constexpr int WM_ROUNDS = 14;                                 // 4 waves x 14 rounds = 56 chunks
-constexpr int WM_TILE_WORDS = (WM_THREADS / 64) * WM_ROUNDS;  // 56 = 8 rank blocks x 7 chunks
-constexpr int WM_TILE = WM_TILE_WORDS * 64;                   // 3584 positions
+constexpr int WM_ROUNDS = 12;                                 // 4 waves x 12 rounds = 48 chunks
+constexpr int WM_TILE_WORDS = (WM_THREADS / 64) * WM_ROUNDS;  // 48 = 16 rank blocks x 3 chunks
+constexpr int WM_TILE_BLOCKS = WM_TILE_WORDS / WM_CHUNKS;
+constexpr int WM_TILE = WM_TILE_WORDS * 64;                   // 3072 positions
+static_assert(WM_TILE_WORDS % WM_CHUNKS == 0, "a tile holds whole rank blocks");
 
 // The code of position idx on this level.  Level 0 reads L itself (raw symbols;
 // the foreign symbol at `hidden` and anything below min_sym become code 0),
@@ -119,8 +121,9 @@ __global__ void __launch_bounds__(WM_THREADS)
     c2 += __popcll(b1 & ~b0 & v);
     c3 += __popcll(b1 & b0 & v);
     if (lane == 0) {
-      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(plane + ((u64)blockIdx.x * 8 + wi / 7) * WM_BLOCK_WORDS + 2 +
-                                                       2 * (wi % 7));
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(plane + ((u64)blockIdx.x * WM_TILE_BLOCKS + wi / WM_CHUNKS) *
+                                                                   WM_BLOCK_WORDS +
+                                                       2 + 2 * (wi % WM_CHUNKS));
       *dst = make_ulonglong2(b0, b1);
     }
   }
@@ -197,7 +200,7 @@ struct BlockDigitsIn {
     const u64 *p = plane + b * WM_BLOCK_WORDS + 2;
     U4 s = SumU4::identity();
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
+    for (int k = 0; k < (int)WM_CHUNKS; k++) {
       u64 lo = p[2 * k], hi = p[2 * k + 1];
       s.v[0] += __popcll(~hi & ~lo);
       s.v[1] += __popcll(~hi & lo);
@@ -258,7 +261,7 @@ void build_wavelet(Ctx &c, Block &blk) {
   const int levels = (bits + 1) / 2;
   Phase ph(c, "wavelet_build", (double)m * levels * 3.3);
   const u32 tiles = (u32)(m / WM_TILE) + 1;
-  const u64 n_blk = (u64)tiles * 8;
+  const u64 n_blk = (u64)tiles * WM_TILE_BLOCKS;
   WaveletDev &wm = blk.wm;
   wm.levels = levels;
   wm.min_sym = min_sym;
