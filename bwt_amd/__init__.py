@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbwt_hip.so")
+LIB_PATH = os.environ.get("BWT_HIP_LIB") or os.path.join(_HERE, "lib", "libbwt_hip.so")  # the variable is for A/B experiments with a variant build
 
 _u8p = C.POINTER(C.c_uint8)
 _i64p = C.POINTER(C.c_int64)

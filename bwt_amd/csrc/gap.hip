@@ -46,6 +46,29 @@ __device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 x, u64
 
 constexpr int CHAIN_THREADS = 256;
 
+// Backward sequential reader of the text.  A chain's text positions are 1024 bytes away from its
+// neighbours', so a byte load per step would touch a different cache line in every lane and find it
+// evicted 16 steps later; instead each lane keeps the aligned 16-byte block around its position in
+// registers.  (An aligned 16-byte block never straddles a page, so reading the whole block of a
+// valid byte is safe at the ends of the text.)
+struct TextBack {
+  const u8 *T;
+  uintptr_t held;
+  uint4 blk;
+  __device__ __forceinline__ explicit TextBack(const u8 *t) : T(t), held(~(uintptr_t)0), blk(make_uint4(0, 0, 0, 0)) {}
+  __device__ __forceinline__ u32 operator()(u64 j) {
+    const uintptr_t ad = reinterpret_cast<uintptr_t>(T + j);
+    const uintptr_t b = ad & ~(uintptr_t)15;
+    if (b != held) {
+      blk = *reinterpret_cast<const uint4 *>(b);
+      held = b;
+    }
+    const u32 k = (u32)(ad & 15), ws = k >> 2;
+    const u32 wd = ws == 0 ? blk.x : (ws == 1 ? blk.y : (ws == 2 ? blk.z : blk.w));
+    return (wd >> ((k & 3) * 8)) & 255u;
+  }
+};
+
 __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
   __shared__ u32 base_s[256];
   base_s[threadIdx.x] = P.lf_tab[threadIdx.x];
@@ -58,6 +81,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
   const u64 j0 = end - 1;
   const u32 e_char = P.e_char, e_rank = P.e_rank;
 
+  TextBack text(T);
   // interval phase: positions E-1 .. j0
   u32 lo, hi;
   u64 ell = P.warm;
@@ -67,7 +91,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
     lo = 0;
     hi = P.m;
     for (u64 j = E; j-- > j0;) {
-      u32 c = T[j];
+      u32 c = text(j);
       if (c == 0) {  // the sentinel suffix is smaller than every left suffix
         lo = hi = 0;
         continue;
@@ -91,7 +115,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
   gout[0] = g;
   u32 step = 1;
   for (u64 j = j0; j-- > begin; step++) {
-    u32 c = T[j];
+    u32 c = text(j);
     u32 kk = wm_lf(P.wm, base_s, c, g);
     if (c == e_char && kk >= e_rank) {
       if (suffix_less(T, P.lb - 1, j)) kk++;
@@ -174,9 +198,17 @@ __global__ void __launch_bounds__(GH_THREADS)
   }
   __syncthreads();
   const u32 lo = bounds[0], hi = bounds[1];
-  for (u32 i = lo + tid; i < hi; i += GH_THREADS) {
-    u32 g = keys[i];
-    if (g <= m) atomicAdd(&hist[g & (width - 1)], 1u);  // LDS counter; fillers (m+1) are skipped
+  // eight independent loads in flight per thread before the first LDS update
+  for (u32 i0 = lo + tid; i0 < hi; i0 += 8 * GH_THREADS) {
+    u32 g[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 i = i0 + k * GH_THREADS;
+      g[k] = i < hi ? keys[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (g[k] <= m) atomicAdd(&hist[g[k] & (width - 1)], 1u);  // LDS counter; fillers (m+1) are skipped
   }
   __syncthreads();
   // inclusive scan of the counters: each thread owns width/256 consecutive ones

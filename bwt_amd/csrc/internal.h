@@ -169,9 +169,12 @@ struct TextKeys {
   u64 n, a;
   int w, K0;
 };
-// With `text`, the first pass takes keys and values from it instead of keys[0]/vals[0] (use 0 only).
-int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1,
-                   const TextKeys *text = nullptr);
+int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
+// Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
+// Keys are stored split: buffer b holds the low words at ((u32*)keys[b])[0..n) and the high words
+// `stride` 32-bit words further.  Returns the buffer that holds the result.
+int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride, int begin_bit,
+                        const TextKeys &text);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------

@@ -44,8 +44,19 @@ struct TieHeadOp {
   }
 };
 
+// 64-bit keys held as one array, or split into low and high words (the layout of the round-0 sort)
+struct PlainKeys {
+  const u64 *p;
+  __device__ __forceinline__ u64 operator[](size_t i) const { return p[i]; }
+};
+struct SplitKeys {
+  const u32 *lo, *hi;
+  __device__ __forceinline__ u64 operator[](size_t i) const { return ((u64)hi[i] << 32) | lo[i]; }
+};
+
+template <class Keys>
 struct GroupIn {
-  const u64 *key;
+  Keys key;
   size_t n;
   u64 mask;  // the key bits that count
   __device__ __forceinline__ TieHead operator()(size_t i) const {
@@ -122,19 +133,28 @@ __global__ void k_comp_text(const u8 *__restrict__ T, u64 n, const u32 *__restri
   pout[k] = p;
 }
 
-// doubling round: composite = group << 32 | (rank of suffix pos+h, plus one; 0 past the window)
-__global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64 n,
+// doubling round at depth h: composite = group << 32 | (rank of suffix pos+h, plus one; 0 past the text)
+//
+// rank[q] at depth h is exact when the h symbols from q lie inside the window (q + h <= e), or when
+// h <= h_exact, the depth the ranks reached by reading the text itself (round 0 and the text rounds).
+// A position whose look-up is not exact cannot be placed by this window: a leaf position raises
+// `overflow` (the caller retries with a longer window); a position of the slack beyond the leaf is
+// retired with a key of its own, so that it leaves the active list.  Its rank is then arbitrary inside
+// its group, which is harmless: by the rule above nothing exact ever reads it.
+__global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64 n, u64 h_exact,
                            const u32 *__restrict__ pos, const u32 *__restrict__ grp, u32 M, u64 h,
                            u64 *__restrict__ comp, u32 *__restrict__ pout, u32 *__restrict__ overflow) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   u32 p = pos[k];
   u64 q = (u64)p + h;
-  u32 sec = 0;
-  if (q < e) {
-    sec = isa[q - a] + 1;
-  } else if (p < b && e < n) {
-    *overflow = 1;  // a leaf suffix needs text ranks beyond the window
+  u64 need = h > h_exact ? q + h : q + 1;  // end of the stretch that must lie inside the window
+  u32 sec;
+  if (e < n && need > e) {
+    if (p < b) *overflow = 1;
+    sec = 0xFFFFFFFFu - (u32)(p - a);  // unique among the retired
+  } else {
+    sec = q < e ? isa[q - a] + 1 : 0u;  // q >= e only when e == n: the empty suffix is the smallest
   }
   comp[k] = ((u64)grp[k] << 32) | sec;
   pout[k] = p;
@@ -162,7 +182,7 @@ struct LeafEmit {
   u8 *L;             // may be null: suffix array only
   u32 *samp_rank, *samp_pos, *special;
   u32 *sa_out;       // may be null
-  const u64 *keys;   // sorted round-0 keys of the window
+  SplitKeys keys;    // sorted round-0 keys of the window
   const u32 *sa;     // sorted window positions
   u64 N;             // window length
   u64 sym_mask;      // symbol field of a key
@@ -235,7 +255,7 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
 // refinement rounds, which only touch the tied ones.  Take the fewest passes for
 // which a random text of this alphabet would leave under 2 % tied.
 static int choose_k0(int w, int max_sym, u64 N) {
-  const int kmax = (64 - w) / w;
+  const int kmax = 56 / w;  // the low 8 key bits hold the preceding symbol and are not sorted on
   const double sigma = max_sym < 2 ? 2.0 : (double)max_sym;
   for (int passes = 1; passes * 8 <= kmax * w + 7; passes++) {
     int k = passes * 8 / w;
@@ -255,22 +275,24 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   const int w = c.sym_bits;
   const int K0 = choose_k0(w, c.max_sym, N);
   const int K1 = 32 / w;
-  const int low_bit = 64 - K0 * w;
+  const int low_bit = 64 - K0 * w;  // >= 8
   const u64 sym_mask = ~0ull << low_bit;
-  DBuf<u64> kb0(c, N), kb1(c, N);
+  const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
+  DBuf<u64> kb0(c, stride), kb1(c, stride);
   DBuf<u32> sb0(c, N), sb1(c, N);
   u64 *keys[2] = {kb0.get(), kb1.get()};
   u32 *vals[2] = {sb0.get(), sb1.get()};
   int cur;
   {
     // round 0: the first pass rolls its keys (symbols | preceding symbol) out of the text
-    int passes = (64 - low_bit + 7) / 8;
-    Phase ph(c, "leaf_radix_sort", (double)N * (passes * 32 - 19));
+    // whole digits, so that none straddles the two key words; the extra low bits are zero padding
+    const int begin_bit = low_bit & ~7;
+    int passes = (64 - begin_bit) / 8;
+    Phase ph(c, "leaf_radix_sort", (double)N * (passes * 28 - 15));
     TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0};
-    c.sort_tag = "leaf:";
-    cur = radix_sort_u64(c, keys, vals, N, low_bit, 64, 0, &tk);
-    c.sort_tag = "";
+    cur = leaf_sort_text_keys(c, keys, vals, N, stride, begin_bit, tk);
   }
+  const SplitKeys sorted_keys{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride};
   u32 *sa = vals[cur];
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
@@ -283,20 +305,21 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   u32 M;
   {
     Phase ph(c, "leaf_group", (double)N * 16);
-    scan_generic<TieHead, TieHeadOp>(c, N, GroupIn{keys[cur], N, sym_mask},
+    scan_generic<TieHead, TieHeadOp>(c, N, GroupIn<SplitKeys>{sorted_keys, N, sym_mask},
                                      FirstListOut{sa, wl_slot, wl_pos, wl_grp, d_total, N});
     M = read_u32(c, d_total);
   }
   u64 h = (u64)K0;
   int round = 0;
   DBuf<u32> isa;
+  u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
   while (M > 0) {
     // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
     // doubling rounds double it but need the inverse array of the whole window (one random write per
     // window position).  Sparse ties get a few text rounds first; dense or deep ties go to doubling.
-    const bool text_round = !isa.get() && (round == 0 || (round < 8 && (u64)M * 16 < N));
+    const bool text_round = !isa.get() && round < 8 && (u64)M * 16 < N;
     Phase ph(c, text_round ? "leaf_text_round" : "leaf_doubling_round", (double)M * 8 * 32);
     DBuf<u64> ck0(c, M), ck1(c, M);
     DBuf<u32> cp0(c, M), cp1(c, M);
@@ -305,6 +328,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
                          wl_grp, M, (u32)h, w, K1, ck0.get(), cp0.get());
     } else {
       if (!isa.get()) {
+        h_exact = h;
         isa = DBuf<u32>(c, N);
         hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa, (u32)a, (u32)N,
                            isa.get());
@@ -312,7 +336,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
                            (u32)a, isa.get());
       }
       hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, isa.get(), (u64)a, (u64)b,
-                         (u64)e, (u64)c.n, wl_pos, wl_grp, M, h, ck0.get(), cp0.get(), d_overflow);
+                         (u64)e, (u64)c.n, h_exact, wl_pos, wl_grp, M, h, ck0.get(), cp0.get(), d_overflow);
     }
     HIP_CHECK(hipGetLastError());
     u64 *ck[2] = {ck0.get(), ck1.get()};
@@ -322,7 +346,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     c.sort_tag = "";
     DBuf<u32> ns(c, M), np(c, M), ng(c, M);
     scan_generic<TieHead, TieHeadOp>(
-        c, M, GroupIn{ck[cc], M, ~0ull},
+        c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull},
         RefineOut{wl_slot, cp[cc], sa, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
     M = read_u32(c, d_total);
     nl_slot = std::move(ns);
@@ -342,7 +366,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   DBuf<u32> res;
   if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
   em.sa_out = sa_out ? res.get() : nullptr;
-  em.keys = keys[cur];
+  em.keys = sorted_keys;
   em.sa = sa;
   em.N = N;
   em.sym_mask = sym_mask;
