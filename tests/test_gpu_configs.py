@@ -83,3 +83,24 @@ def test_ascii_letters_min_sym_offset(ctx):
     T = gen_text(120000, 3, 26)
     T[:-1] += ord("a") - 1
     _same_as_oracle(ctx, T, ord("z"), 20000, 700, 200)
+
+
+@pytest.mark.parametrize("unit,copies,rate", [(700, 40, 0.0), (3000, 20, 0.001), (5000, 12, 0.0005), (37, 500, 0.0)])
+def test_leaf_windows_on_long_repeats(ctx, unit, copies, rate):
+    """Leaves in the middle of a text whose repeats are longer than the sort window's slack (4096 symbols here):
+    the suffix array of each leaf must still be the full-text order (include/suffix_array.h:14-49)."""
+    T = gen_repetitive(unit, copies, rate, seed=5, sigma=4)
+    n = len(T)
+    ctx.set_text(T)
+    m = min(7000, n // 3)
+    for a, b in [(0, m), (n // 3, n // 3 + m), (n - m - 1500, n - 1500), (n - m, n)]:
+        assert (ctx.leaf_sa(a, b) == Oracle.sa_range(T, a, b)).all(), (unit, copies, a, b)
+
+
+def test_few_distinct_symbols_in_a_wide_alphabet(ctx):
+    """Four letters with large codes ('a'..'d'): the round-0 key holds few symbols, nearly all suffixes tie and
+    the doubling rounds start immediately; with several leaves the windows end inside runs of ties."""
+    rng = np.random.default_rng(11)
+    T = np.concatenate([rng.integers(97, 101, size=150000, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
+    _same_as_oracle(ctx, T, 100, 20000, 500)
+    _same_as_oracle(ctx, T, 100, 3000, 500, 64)
