@@ -22,8 +22,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec); ~6300 GB/s is what a copy kernel reaches
-
 
 def cpu_baseline(budget_n):
     """The reference itself (oracle/_ref, serial build) or, without it, the C oracle, on a bounded sample."""
@@ -103,25 +101,9 @@ def main():
     ctx.set_timing(0)
     mem = ctx.mem_stats()
 
-    # roofline of the dominant kernel: the leaf sort's scatter pass (reads key+index, writes key+index)
-    roof = None
-    dom = "leaf:k_rs_scatter_u64_pairs"
-    if dom in timers and timers[dom][2] > 0:
-        ms, work, calls = timers[dom]
-        achieved = work / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_rs_scatter<u64,pairs>",
-                "bytes_per_launch": work / calls, "avg_launch_ms": round(ms / calls, 4), "launches": calls}
-    # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE and WRITE_SIZE in
-    # separate rocprofv3 runs, FETCH_SIZE doubled as the gfx950 guide prescribes); only for the workload they were taken on
-    tfile = os.path.join(ROOT, "profiles", "r1_traffic_rs_scatter.json")
-    if roof and os.path.exists(tfile):
-        t = json.load(open(tfile))
-        if t["workload"] == {"n": n, "leaves": args.leaves}:
-            roof["traffic"] = t["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r1_traffic_rs_scatter.json"
-    phases = {k: {"ms_per_step": round(v[0] / args.steps, 3), "work_per_step": v[1] / args.steps, "calls": v[2]}
-              for k, v in sorted(timers.items(), key=lambda kv: -kv[1][0])}
+    from bwt_amd.benchutil import phase_table, roofline
+    roof = roofline(timers, ROOT, {"n": n, "leaves": args.leaves})
+    phases = phase_table(timers, args.steps)
     out = {
         "metric": "BWT build Mbase/s end-to-end", "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),

@@ -273,7 +273,8 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
   P.lf_tab = l.wm.lf_base.get();
   P.g = g0.get();
   {
-    Phase ph(c, "gap_chains", (double)rn * (l.wm.levels + 1));  // random line transactions
+    // 64-byte random reads: one rank block per level and step, one 16-byte text block every 16 steps
+    Phase ph(c, "gap_chains", (double)rn * l.wm.levels + (double)rn / 16);
     hipLaunchKernelGGL(k_chains, dim3(ceil_div(G.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
   }

@@ -7,15 +7,26 @@
 //   Op  struct { static T identity(); static T apply(T earlier, T later); }
 //       associative
 //   In  struct { __device__ T operator()(size_t i) const; }
+//       optionally also  void vec4(size_t i0, T out[4]) const  for four consecutive
+//       inputs starting at a multiple of four (all below n), e.g. through 16-byte loads
 //   Out struct { __device__ void operator()(size_t i, T excl, T incl) const; }
 //
 // HBM traffic: whatever In reads, twice, plus whatever Out writes.
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "device_utils.h"
 #include "internal.h"
 
 namespace bwtamd {
+
+template <class In, class T, class = void>
+struct has_vec4 : std::false_type {};
+template <class In, class T>
+struct has_vec4<In, T, std::void_t<decltype(std::declval<const In &>().vec4((size_t)0, (T *)nullptr))>>
+    : std::true_type {};
 
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_VEC = 4;     // consecutive items per thread per round
@@ -67,6 +78,20 @@ __device__ __forceinline__ void block_scan_any(T v, T *smem, T &excl, T &incl, T
   total = tot;
 }
 
+// the SCAN_VEC inputs of one thread and round; identity beyond n
+template <class T, class Op, class In>
+__device__ __forceinline__ void scan_load(const In &in, size_t i0, size_t n, T (&v)[SCAN_VEC]) {
+  static_assert(SCAN_VEC == 4, "vec4 inputs");
+  if constexpr (has_vec4<In, T>::value) {
+    if (i0 + SCAN_VEC <= n) {
+      in.vec4(i0, v);
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SCAN_VEC; k++) v[k] = (i0 + k < n) ? in(i0 + k) : Op::identity();
+}
+
 template <class T, class Op, class In>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(size_t n, In in, T *tile_agg) {
   __shared__ T smem[SCAN_THREADS / 64];
@@ -76,10 +101,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(size_t n, In in, T
 #pragma unroll
   for (int r = 0; r < SCAN_ROUNDS; r++) {
     size_t i0 = base + ((size_t)r * SCAN_THREADS + threadIdx.x) * SCAN_VEC;
+    T v[SCAN_VEC];
+    scan_load<T, Op, In>(in, i0, n, v);
     T mine = Op::identity();
 #pragma unroll
-    for (int k = 0; k < SCAN_VEC; k++)
-      if (i0 + k < n) mine = Op::apply(mine, in(i0 + k));
+    for (int k = 0; k < SCAN_VEC; k++) mine = Op::apply(mine, v[k]);
     T e, i, tot;
     block_scan_any<T, Op>(mine, smem, e, i, tot);
     tile_tot = Op::apply(tile_tot, tot);
@@ -97,12 +123,10 @@ __global__ void __launch_bounds__(SCAN_THREADS)
   for (int r = 0; r < SCAN_ROUNDS; r++) {
     size_t i0 = base + ((size_t)r * SCAN_THREADS + threadIdx.x) * SCAN_VEC;
     T v[SCAN_VEC];
+    scan_load<T, Op, In>(in, i0, n, v);
     T mine = Op::identity();
 #pragma unroll
-    for (int k = 0; k < SCAN_VEC; k++) {
-      v[k] = (i0 + k < n) ? in(i0 + k) : Op::identity();
-      mine = Op::apply(mine, v[k]);
-    }
+    for (int k = 0; k < SCAN_VEC; k++) mine = Op::apply(mine, v[k]);
     T excl, incl, tot;
     block_scan_any<T, Op>(mine, smem, excl, incl, tot);
     T run = Op::apply(carry, excl);

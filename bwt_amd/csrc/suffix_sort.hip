@@ -50,8 +50,16 @@ struct PlainKeys {
   __device__ __forceinline__ u64 operator[](size_t i) const { return p[i]; }
 };
 struct SplitKeys {
-  const u32 *lo, *hi;
+  const u32 *lo, *hi;  // both 16-byte aligned
   __device__ __forceinline__ u64 operator[](size_t i) const { return ((u64)hi[i] << 32) | lo[i]; }
+  // keys i0 .. i0+3, i0 a multiple of four
+  __device__ __forceinline__ void load4(size_t i0, u64 (&k)[4]) const {
+    const uint4 l = *reinterpret_cast<const uint4 *>(lo + i0), h = *reinterpret_cast<const uint4 *>(hi + i0);
+    k[0] = ((u64)h.x << 32) | l.x;
+    k[1] = ((u64)h.y << 32) | l.y;
+    k[2] = ((u64)h.z << 32) | l.z;
+    k[3] = ((u64)h.w << 32) | l.w;
+  }
 };
 
 template <class Keys>
@@ -64,6 +72,33 @@ struct GroupIn {
     bool head = (i == 0) || (key[i - 1] & mask) != k;
     bool next_head = (i + 1 == n) || (key[i + 1] & mask) != k;
     return TieHead{(u32)!(head && next_head), head ? (u32)(i + 1) : 0u};
+  }
+};
+
+// the same for four consecutive elements of split keys: two 16-byte loads and the two neighbours
+template <>
+struct GroupIn<SplitKeys> {
+  SplitKeys key;
+  size_t n;
+  u64 mask;
+  __device__ __forceinline__ TieHead operator()(size_t i) const {
+    u64 k = key[i] & mask;
+    bool head = (i == 0) || (key[i - 1] & mask) != k;
+    bool next_head = (i + 1 == n) || (key[i + 1] & mask) != k;
+    return TieHead{(u32)!(head && next_head), head ? (u32)(i + 1) : 0u};
+  }
+  __device__ __forceinline__ void vec4(size_t i0, TieHead *out) const {
+    u64 k[6], c[4];
+    key.load4(i0, c);
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j + 1] = c[j] & mask;
+    k[0] = i0 ? (key[i0 - 1] & mask) : ~k[1];
+    k[5] = (i0 + 4 < n) ? (key[i0 + 4] & mask) : ~k[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bool head = k[j] != k[j + 1], next_head = k[j + 1] != k[j + 2];
+      out[j] = TieHead{(u32)!(head && next_head), head ? (u32)(i0 + j + 1) : 0u};
+    }
   }
 };
 
@@ -188,16 +223,10 @@ struct LeafEmit {
   u64 sym_mask;      // symbol field of a key
   u32 prev_mask;     // preceding-symbol field
 
-  // window rank i holds leaf rank r
-  __device__ __forceinline__ void emit(u64 r, u64 i) const {
-    u32 pos = sa[i];
-    if (sa_out) sa_out[r] = pos;
-    if (!L) return;
-    u64 k = keys[i];
-    u64 top = k & sym_mask;
-    bool tied = (i > 0 && (keys[i - 1] & sym_mask) == top) || (i + 1 < N && (keys[i + 1] & sym_mask) == top);
-    // a suffix that round 0 placed still sits next to its key; a refined one moved, so read the text
-    L[r] = tied ? (pos ? T[pos - 1] : T[n - 1]) : (u8)((u32)k & prev_mask);
+  double samp_ratio; // (ns-1)/(m-1), only used to skip positions that are certainly not sampled
+
+  // special ranks and samples of the suffix at `pos`, which has leaf rank r
+  __device__ __forceinline__ void note(u64 r, u32 pos) const {
     if (pos == a) special[0] = (u32)r;          // s_rank
     if (pos + 1 == a + m) special[1] = (u32)r;  // e_rank
     if (m == 1) {
@@ -208,8 +237,16 @@ struct LeafEmit {
     // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
     // order, so the sample arrays come out sorted by position without a sort.  The two floor()
     // expressions are the reference's own (include/bwt.h:339-340), evaluated in IEEE double as
-    // there: 64-bit integer product, one conversion, one correctly rounded division.
+    // there: 64-bit integer product, one conversion, one correctly rounded division.  Divisions are
+    // slow and most positions are not sampled: position i is sampled iff the fractional part of
+    // i*(ns-1)/(m-1) is below (ns-1)/(m-1), so one multiplication (error far below the 2^-16
+    // margin for any ns < 2^36) rules out the rest.
     i64 rel = (i64)(pos - a);
+    if (rel != 0) {
+      double t = (double)rel * samp_ratio;
+      double f = t - floor(t);
+      if (f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16) return;
+    }
     i64 A = ns - 1;
     double D = (double)(i64)(m - 1);
     i64 x = (i64)floor((double)((rel - 1) * A) / D);
@@ -219,17 +256,68 @@ struct LeafEmit {
       samp_pos[y] = pos;
     }
   }
+
+  __device__ __forceinline__ u8 sym_before(u32 pos) const { return pos ? T[pos - 1] : T[n - 1]; }
+
+  // window rank i holds leaf rank r
+  __device__ __forceinline__ void emit(u64 r, u64 i) const {
+    u32 pos = sa[i];
+    if (sa_out) sa_out[r] = pos;
+    if (!L) return;
+    u64 k = keys[i];
+    u64 top = k & sym_mask;
+    bool tied = (i > 0 && (keys[i - 1] & sym_mask) == top) || (i + 1 < N && (keys[i + 1] & sym_mask) == top);
+    // a suffix that round 0 placed still sits next to its key; a refined one moved, so read the text
+    L[r] = tied ? sym_before(pos) : (u8)((u32)k & prev_mask);
+    note(r, pos);
+  }
+
+  // window ranks i0 .. i0+3 (i0 a multiple of four, all below N) of a window that is the leaf itself
+  // (leaf rank == window rank): 16-byte loads, one 4-byte store of L
+  __device__ __forceinline__ void emit4(u64 i0) const {
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
+    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
+    if (sa_out) *reinterpret_cast<uint4 *>(sa_out + i0) = p4;
+    if (!L) return;
+    u64 k[6], c[4];
+    keys.load4(i0, c);
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j + 1] = c[j];
+    k[0] = i0 ? keys[i0 - 1] : ~c[0];
+    k[5] = (i0 + 4 < N) ? keys[i0 + 4] : ~c[3];
+    u32 packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u64 top = k[j + 1] & sym_mask;
+      bool tied = (k[j] & sym_mask) == top || (k[j + 2] & sym_mask) == top;
+      u32 ch = tied ? (u32)sym_before(pos[j]) : ((u32)k[j + 1] & prev_mask);
+      packed |= ch << (8 * j);
+      note(i0 + j, pos[j]);
+    }
+    *reinterpret_cast<u32 *>(L + i0) = packed;
+  }
 };
 
 __global__ void k_emit_all(LeafEmit E) {
-  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < E.N) E.emit(r, r);
+  u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 + 4 <= E.N) {
+    E.emit4(i0);
+  } else {
+    for (u64 i = i0; i < E.N; i++) E.emit(i, i);
+  }
 }
 
 struct LeafFilterIn {
   const u32 *sa;
   u32 b;
   __device__ __forceinline__ u32 operator()(size_t i) const { return sa[i] < b; }
+  __device__ __forceinline__ void vec4(size_t i0, u32 *out) const {
+    const uint4 p = *reinterpret_cast<const uint4 *>(sa + i0);
+    out[0] = p.x < b;
+    out[1] = p.y < b;
+    out[2] = p.z < b;
+    out[3] = p.w < b;
+  }
 };
 struct LeafFilterOut {
   LeafEmit E;
@@ -371,10 +459,11 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   em.N = N;
   em.sym_mask = sym_mask;
   em.prev_mask = (1u << w) - 1;
+  em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
   {
     Phase ph(c, "leaf_emit", (double)N * 12 + (double)(b - a) * 2);
     if (e == b) {
-      hipLaunchKernelGGL(k_emit_all, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, em);
+      hipLaunchKernelGGL(k_emit_all, dim3(ceil_div(ceil_div(N, 4), 256)), dim3(256), 0, c.stream, em);
       HIP_CHECK(hipGetLastError());
     } else {
       scan_generic<u32, SumU32>(c, N, LeafFilterIn{sa, (u32)b}, LeafFilterOut{em});

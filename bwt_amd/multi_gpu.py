@@ -159,6 +159,8 @@ def bench_main(args, rank, local_rank, world):
         if blk is not None:
             blk.free()
     ctx.sync()
+    ctx.set_timing(0 if getattr(args, "no_timers", False) else 2)
+    ctx.reset_timers()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -173,7 +175,10 @@ def bench_main(args, rank, local_rank, world):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item()) / args.steps
+    timers = ctx.timers()
+    ctx.set_timing(0)
     if rank == 0:
+        from bwt_amd.benchutil import phase_table, roofline
         th = leaf_threshold(n, total_leaves)
         out = {
             "metric": "BWT build Mbase/s end-to-end", "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
@@ -185,7 +190,9 @@ def bench_main(args, rank, local_rank, world):
                        "n": n, "sigma": args.sigma, "leaves": total_leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                        "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True,
                        "parallelism": "leaf-sharded x%d, pairwise merge tree" % world},
-            "roofline": None, "cpu_baseline": None,
+            # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
+            "roofline": roofline(timers), "cpu_baseline": None,
+            "phases_rank0": phase_table(timers, args.steps),
         }
         print(json.dumps(out))
         sys.stdout.flush()
