@@ -9,6 +9,7 @@
 //   In  struct { __device__ T operator()(size_t i) const; }
 //       optionally also  void vec4(size_t i0, T out[4]) const  for four consecutive
 //       inputs starting at a multiple of four (all below n), e.g. through 16-byte loads
+//   Out may likewise offer  void vec4(size_t i0, const T excl[4], const T incl[4]) const
 //   Out struct { __device__ void operator()(size_t i, T excl, T incl) const; }
 //
 // HBM traffic: whatever In reads, twice, plus whatever Out writes.
@@ -21,6 +22,13 @@
 #include "internal.h"
 
 namespace bwtamd {
+
+template <class Out, class T, class = void>
+struct has_out_vec4 : std::false_type {};
+template <class Out, class T>
+struct has_out_vec4<Out, T,
+                    std::void_t<decltype(std::declval<const Out &>().vec4((size_t)0, (const T *)nullptr, (const T *)nullptr))>>
+    : std::true_type {};
 
 template <class In, class T, class = void>
 struct has_vec4 : std::false_type {};
@@ -130,11 +138,24 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     T excl, incl, tot;
     block_scan_any<T, Op>(mine, smem, excl, incl, tot);
     T run = Op::apply(carry, excl);
+    T ex[SCAN_VEC], inc[SCAN_VEC];
 #pragma unroll
     for (int k = 0; k < SCAN_VEC; k++) {
-      T before = run;
+      ex[k] = run;
       run = Op::apply(run, v[k]);
-      if (i0 + k < n) out(i0 + k, before, run);
+      inc[k] = run;
+    }
+    bool done = false;
+    if constexpr (has_out_vec4<Out, T>::value) {
+      if (i0 + SCAN_VEC <= n) {
+        out.vec4(i0, ex, inc);
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (int k = 0; k < SCAN_VEC; k++)
+        if (i0 + k < n) out(i0 + k, ex[k], inc[k]);
     }
     carry = Op::apply(carry, tot);
   }

@@ -272,29 +272,50 @@ struct LeafEmit {
     note(r, pos);
   }
 
-  // window ranks i0 .. i0+3 (i0 a multiple of four, all below N) of a window that is the leaf itself
-  // (leaf rank == window rank): 16-byte loads, one 4-byte store of L
-  __device__ __forceinline__ void emit4(u64 i0) const {
-    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
-    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
-    if (sa_out) *reinterpret_cast<uint4 *>(sa_out + i0) = p4;
-    if (!L) return;
+  // BWT symbols of window ranks i0 .. i0+3 (i0 a multiple of four, all below N), from 16-byte loads
+  __device__ __forceinline__ void symbols4(u64 i0, const u32 (&pos)[4], u32 (&ch)[4]) const {
     u64 k[6], c[4];
     keys.load4(i0, c);
 #pragma unroll
     for (int j = 0; j < 4; j++) k[j + 1] = c[j];
     k[0] = i0 ? keys[i0 - 1] : ~c[0];
     k[5] = (i0 + 4 < N) ? keys[i0 + 4] : ~c[3];
-    u32 packed = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       u64 top = k[j + 1] & sym_mask;
       bool tied = (k[j] & sym_mask) == top || (k[j + 2] & sym_mask) == top;
-      u32 ch = tied ? (u32)sym_before(pos[j]) : ((u32)k[j + 1] & prev_mask);
-      packed |= ch << (8 * j);
-      note(i0 + j, pos[j]);
+      ch[j] = tied ? (u32)sym_before(pos[j]) : ((u32)k[j + 1] & prev_mask);
     }
-    *reinterpret_cast<u32 *>(L + i0) = packed;
+  }
+
+  // four window ranks of a window that is the leaf itself (leaf rank == window rank): one 4-byte store of L
+  __device__ __forceinline__ void emit4(u64 i0) const {
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
+    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
+    if (sa_out) *reinterpret_cast<uint4 *>(sa_out + i0) = p4;
+    if (!L) return;
+    u32 ch[4];
+    symbols4(i0, pos, ch);
+#pragma unroll
+    for (int j = 0; j < 4; j++) note(i0 + j, pos[j]);
+    *reinterpret_cast<u32 *>(L + i0) = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24);
+  }
+
+  // four window ranks of a longer window: rank[j] is the leaf rank of i0+j where keep[j] says it belongs to the leaf
+  __device__ __forceinline__ void emit4_filtered(u64 i0, const u32 (&rank)[4], const bool (&keep)[4]) const {
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
+    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
+    u32 ch[4] = {0, 0, 0, 0};
+    if (L) symbols4(i0, pos, ch);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!keep[j]) continue;
+      if (sa_out) sa_out[rank[j]] = pos[j];
+      if (L) {
+        L[rank[j]] = (u8)ch[j];
+        note(rank[j], pos[j]);
+      }
+    }
   }
 };
 
@@ -323,6 +344,11 @@ struct LeafFilterOut {
   LeafEmit E;
   __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
     if (in != ex) E.emit(ex, i);
+  }
+  __device__ __forceinline__ void vec4(size_t i0, const u32 *ex, const u32 *in) const {
+    const u32 rank[4] = {ex[0], ex[1], ex[2], ex[3]};
+    const bool keep[4] = {in[0] != ex[0], in[1] != ex[1], in[2] != ex[2], in[3] != ex[3]};
+    E.emit4_filtered(i0, rank, keep);
   }
 };
 
