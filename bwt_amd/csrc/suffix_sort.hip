@@ -8,9 +8,11 @@
 //             (key, position) over the window [a, e), e = b + slack; the first
 //             pass computes the keys from the text on the fly
 //   tie list  suffixes whose key is shared form groups; only those stay active
+//   direct    if ties are sparse, small groups are ordered by comparing the text
+//             itself (on random text this ends the sort); given up as a whole
+//             when a group is large or a comparison runs long
 //   text rnd  active suffixes are ordered inside their group by the next K1
-//             symbols read from the text (no inverse array needed; on random
-//             text this ends the sort)
+//             symbols read from the text (no inverse array needed)
 //   doubling  the inverse suffix array is built once, then every round orders
 //             the active suffixes by (group, rank[pos + h]) and doubles h
 //
@@ -193,6 +195,65 @@ __global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64
   }
   comp[k] = ((u64)grp[k] << 32) | sec;
   pout[k] = p;
+}
+
+// ----------------------------------------------------------------------------
+// direct finish for sparse, shallow ties: every tied suffix counts the members of
+// its (small) group that are smaller, comparing the text itself from depth h on.
+// All or nothing: a group of more than DF_GROUP members or a comparison longer
+// than DF_DEPTH symbols raises `fail` and the regular rounds take over.
+// Comparing the text gives the full-text order whatever the window is.
+// ----------------------------------------------------------------------------
+constexpr u32 DF_GROUP = 32;
+constexpr u32 DF_DEPTH = 512;
+
+__global__ void k_direct_finish(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ pos,
+                                const u32 *__restrict__ grp, u32 M, u64 h, u32 *__restrict__ out_pos,
+                                u32 *__restrict__ fail) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const u32 g = grp[k];
+  u32 lo = k, hi = k;  // group = [lo, hi]
+  while (lo > 0 && grp[lo - 1] == g && k - lo < DF_GROUP) lo--;
+  while (hi + 1 < M && grp[hi + 1] == g && hi - k < DF_GROUP) hi++;
+  if (k - lo >= DF_GROUP || hi - k >= DF_GROUP) {
+    *fail = 1;
+    return;
+  }
+  const u64 x = (u64)pos[k] + h;
+  u32 smaller = 0;
+  for (u32 j = lo; j <= hi; j++) {
+    if (j == k) continue;
+    const u64 y = (u64)pos[j] + h;
+    // is T[y:] < T[x:] ?  Positions at or past n read as the empty suffix, the smallest.
+    bool less = false, decided = false;
+    for (u32 d = 0; d < DF_DEPTH; d++) {
+      const bool ey = y + d >= n, ex = x + d >= n;
+      if (ey || ex) {
+        less = ey && !ex;
+        decided = true;
+        break;
+      }
+      const u32 cy = T[y + d], cx = T[x + d];
+      if (cy != cx) {
+        less = cy < cx;
+        decided = true;
+        break;
+      }
+    }
+    if (!decided) {
+      *fail = 1;
+      return;
+    }
+    smaller += less;
+  }
+  out_pos[lo + smaller] = pos[k];
+}
+
+__global__ void k_direct_commit(const u32 *__restrict__ slot, const u32 *__restrict__ new_pos, u32 M,
+                                u32 *__restrict__ sa) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < M) sa[slot[k]] = new_pos[k];
 }
 
 __global__ void k_isa_init(const u32 *__restrict__ sa, u32 a, u32 N, u32 *__restrict__ isa) {
@@ -429,6 +490,20 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
+  if (M > 0 && (u64)M * 16 < N) {
+    Phase ph(c, "leaf_direct_finish", (double)M * 64 * 2);
+    DBuf<u32> np(c, M);
+    u32 *d_fail = c.d_scalars + 10;
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_direct_finish, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos, wl_grp,
+                       M, h, np.get(), d_fail);
+    HIP_CHECK(hipGetLastError());
+    if (read_u32(c, d_fail) == 0) {
+      hipLaunchKernelGGL(k_direct_commit, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, np.get(), M, sa);
+      HIP_CHECK(hipGetLastError());
+      M = 0;
+    }
+  }
   while (M > 0) {
     // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
     // doubling rounds double it but need the inverse array of the whole window (one random write per
