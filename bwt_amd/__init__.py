@@ -66,6 +66,11 @@ def lib():
         "bwt_hip_block_rank": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_block_LF": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
+        "bwt_hip_dist_bounds": [i64, i32, _i64p],
+        "bwt_hip_dist_chains": [vp, vp, i64, i64, i64, vp],
+        "bwt_hip_dist_partition": [vp, vp, i64, i64, i32, vp, _i64p],
+        "bwt_hip_dist_merge_slice": [vp, vp, i64, vp, i64, vp, vp, vp],
+        "bwt_hip_dist_resample": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, vp, vp, _i64p],
         "bwt_hip_set_timing": [vp, i32],
         "bwt_hip_reset_timers": [vp],
         "bwt_hip_timer_count": [vp],
@@ -98,6 +103,13 @@ def _chk(rc):
 
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+def dist_bounds(m, parts):
+    """First left rank of each of the `parts` parts a merge with a left block of m suffixes is cut into; [parts] = m+1."""
+    lo = np.zeros(parts + 1, dtype=np.int64)
+    _chk(lib().bwt_hip_dist_bounds(m, parts, _p(lo, _i64p)))
+    return lo
 
 
 class Context:
@@ -190,6 +202,28 @@ class Context:
         g = np.empty(r.b - r.a, dtype=np.int64) if want_g else None
         _chk(lib().bwt_hip_gap(self._h, l._h, r._h, build_gap_segment_sz, _p(gap, _i64p), _p(g, _i64p)))
         return gap, g
+
+    # ---- one merge spread over several GPUs (raw device addresses) ----------
+    def dist_chains(self, l, ra, rb, build_gap_segment_sz, g_ptr):
+        _chk(lib().bwt_hip_dist_chains(self._h, l._h, ra, rb, build_gap_segment_sz, C.c_void_p(g_ptr)))
+
+    def dist_partition(self, g_ptr, count, m, parts, out_ptr):
+        counts = np.zeros(parts, dtype=np.int64)
+        _chk(lib().bwt_hip_dist_partition(self._h, C.c_void_p(g_ptr), count, m, parts, C.c_void_p(out_ptr), _p(counts, _i64p)))
+        return counts
+
+    def dist_merge_slice(self, lL_ptr, mL, rL_ptr, rn, g_ptr, out_ptr, S_ptr):
+        _chk(lib().bwt_hip_dist_merge_slice(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),
+                                            C.c_void_p(out_ptr), C.c_void_p(S_ptr)))
+
+    def dist_resample(self, l_rank_ptr, l_pos_ptr, nl, r_rank_ptr, r_pos_ptr, nr, a, c, ns_out, S_ptr, i_lo, i_hi,
+                      right_before, g_ptr, p_lo, p_hi, o_rank_ptr, o_pos_ptr):
+        kept = C.c_int64(0)
+        vp = C.c_void_p
+        _chk(lib().bwt_hip_dist_resample(self._h, vp(l_rank_ptr), vp(l_pos_ptr), nl, vp(r_rank_ptr), vp(r_pos_ptr), nr, a, c,
+                                         ns_out, vp(S_ptr), i_lo, i_hi, right_before, vp(g_ptr), p_lo, p_hi,
+                                         vp(o_rank_ptr), vp(o_pos_ptr), C.byref(kept)))
+        return kept.value
 
     # ---- observability ----------------------------------------------------
     def set_timing(self, level):

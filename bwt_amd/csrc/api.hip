@@ -304,12 +304,12 @@ int bwt_hip_block_import_device(bwt_hip_ctx *ctx, int64_t a, int64_t b, const ui
                                 int64_t e_rank, const int64_t *rank_dev, const int64_t *pos_dev, int64_t ns,
                                 bwt_hip_block **out) {
   API_BEGIN
-  need(ctx && L_dev && out && rank_dev && pos_dev, "ctx, L_dev, samp_rank_dev, samp_pos_dev, out");
+  need(ctx && L_dev && out && (ns == 0 || (rank_dev && pos_dev)), "ctx, L_dev, samp_rank_dev, samp_pos_dev, out");
   Ctx &c = ctx->c;
   need(c.T != nullptr, "no text set");
   need(a >= 0 && a < b && b <= c.n, "0 <= a < b <= n");
   need(s_rank >= a && s_rank < b && e_rank >= a && e_rank < b, "ranks inside [a,b)");
-  need(ns >= 1, "n_samples >= 1");
+  need(ns >= 0, "n_samples >= 0 (0: a block that only serves as the left side of LF chains)");
   HIP_CHECK(hipSetDevice(c.device));
   std::unique_ptr<Block> blk(new Block());
   blk->a = a;
@@ -317,13 +317,15 @@ int bwt_hip_block_import_device(bwt_hip_ctx *ctx, int64_t a, int64_t b, const ui
   blk->s_rank = s_rank - a;
   blk->e_rank = e_rank - a;
   blk->L = DBuf<u8>(c, (size_t)(b - a));
-  blk->samp_rank = DBuf<u32>(c, (size_t)ns);
-  blk->samp_pos = DBuf<u32>(c, (size_t)ns);
+  blk->samp_rank = DBuf<u32>(c, (size_t)(ns ? ns : 1));
+  blk->samp_pos = DBuf<u32>(c, (size_t)(ns ? ns : 1));
   blk->n_samp = ns;
   HIP_CHECK(hipMemcpyAsync(blk->L.get(), L_dev, (size_t)(b - a), hipMemcpyDeviceToDevice, c.stream));
-  hipLaunchKernelGGL(k_narrow_samples, dim3(ceil_div(ns, 256)), dim3(256), 0, c.stream, rank_dev, pos_dev, (u32)ns, a,
-                     blk->samp_rank.get(), blk->samp_pos.get());
-  HIP_CHECK(hipGetLastError());
+  if (ns > 0) {
+    hipLaunchKernelGGL(k_narrow_samples, dim3(ceil_div(ns, 256)), dim3(256), 0, c.stream, rank_dev, pos_dev, (u32)ns, a,
+                       blk->samp_rank.get(), blk->samp_pos.get());
+    HIP_CHECK(hipGetLastError());
+  }
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
   c.sync();
   blk->e_char = *(u8 *)c.h_scalars;
@@ -483,6 +485,97 @@ int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l_, bwt_hip_block *r_, int64_t 
     HIP_CHECK(hipMemcpyAsync(g.data(), G.g_text.get(), rn * 4, hipMemcpyDeviceToHost, c.stream));
     c.sync();
     for (size_t j = 0; j < rn; j++) g_out[j] = l.a + (i64)g[j];
+  }
+  API_END
+}
+
+// ---------------------------------------------------------------------------
+// a merge spread over several GPUs
+// ---------------------------------------------------------------------------
+int bwt_hip_dist_bounds(int64_t m, int parts, int64_t *lo) {
+  API_BEGIN
+  need(m >= 0 && parts >= 1 && parts <= 256 && lo, "m >= 0, 1 <= parts <= 256, lo");
+  partition_bounds((u64)m, (u32)parts, lo);
+  API_END
+}
+
+int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l_, int64_t ra, int64_t rb, int64_t seg, uint32_t *g_dev) {
+  API_BEGIN
+  need(ctx && l_ && g_dev, "ctx, l, g_dev");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  DBuf<u32> g0;
+  ChainLayout lay = run_chains(c, *as_block(l_), ra, rb, seg, g0);
+  chains_text_order(c, lay, g0.get(), g_dev);
+  c.sync();
+  API_END
+}
+
+int bwt_hip_dist_partition(bwt_hip_ctx *ctx, const uint32_t *g_dev, int64_t count, int64_t m, int parts,
+                           uint32_t *out_dev, int64_t *counts) {
+  API_BEGIN
+  need(ctx && counts && count >= 0 && m >= 0, "ctx, counts, count >= 0, m >= 0");
+  need(count == 0 || (g_dev && out_dev), "g_dev, out_dev");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  partition_by_left_rank(c, g_dev, (u64)count, (u64)m, (u32)parts, out_dev, counts);
+  API_END
+}
+
+int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
+                             uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev) {
+  API_BEGIN
+  need(ctx && S_dev && mL >= 0 && rn >= 0, "ctx, S_dev, mL >= 0, rn >= 0");
+  need((mL == 0 || lL_dev) && (rn == 0 || (rL_dev && g_dev)) && (mL + rn == 0 || out_dev), "device buffers");
+  need(mL + rn < (int64_t)((1ull << 32) - 2), "slice below 2^32-2 symbols");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  DBuf<u32> scratch(c, (size_t)(rn > 0 ? rn : 1));
+  gap_prefix(c, g_dev, scratch.get(), (u64)rn, (u64)mL, S_dev);
+  merge_symbols(c, lL_dev, (u64)mL, rL_dev, (u64)rn, S_dev, out_dev);
+  c.sync();
+  API_END
+}
+
+int bwt_hip_dist_resample(bwt_hip_ctx *ctx, const int64_t *l_rank_dev, const int64_t *l_pos_dev, int64_t nl,
+                          const int64_t *r_rank_dev, const int64_t *r_pos_dev, int64_t nr, int64_t a, int64_t cpos,
+                          int64_t ns_out, const uint32_t *S_dev, int64_t i_lo, int64_t i_hi, int64_t right_before,
+                          const uint32_t *g_dev, int64_t p_lo, int64_t p_hi, int64_t *o_rank_dev, int64_t *o_pos_dev,
+                          int64_t *kept) {
+  API_BEGIN
+  need(ctx && kept && nl >= 0 && nr >= 0 && ns_out >= 1, "ctx, kept, nl >= 0, nr >= 0, ns_out >= 1");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  const u64 nn = (u64)(nl + nr);
+  ResamplePart R;
+  R.l_rank = l_rank_dev;
+  R.l_pos = l_pos_dev;
+  R.nl = (u64)nl;
+  R.r_rank = r_rank_dev;
+  R.r_pos = r_pos_dev;
+  R.nr = (u64)nr;
+  R.a = a;
+  R.cc = cpos;
+  R.A = (u64)(ns_out - 1);
+  R.B = nn ? nn - 1 : 0;
+  R.S_local = S_dev;
+  R.i_lo = (u64)i_lo;
+  R.i_hi = (u64)i_hi;
+  R.right_before = (u64)right_before;
+  R.g_local = g_dev;
+  R.p_lo = (u64)p_lo;
+  R.p_hi = (u64)p_hi;
+  R.o_rank = o_rank_dev;
+  R.o_pos = o_pos_dev;
+  u64 k = nn;
+  if (nn >= 1) {
+    u64 t = 1 + (R.B ? ((nn - 1) * R.A) / R.B : 0);
+    k = t < nn ? t : nn;
+  }
+  *kept = (i64)k;
+  if (o_rank_dev && o_pos_dev) {
+    resample_part(c, R);
+    c.sync();
   }
   API_END
 }

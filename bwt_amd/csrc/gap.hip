@@ -234,28 +234,34 @@ static int bits_for(u64 x) {
   return b;
 }
 
-GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
-  if (l.b != r.a) fail(BWT_HIP_EINVAL, "blocks are not adjacent: [%ld,%ld) and [%ld,%ld)", (long)l.a, (long)l.b,
-                       (long)r.a, (long)r.b);
+// LF-mapping chains of the right positions [ra, rb) against the block l (ra >= l.b; the positions need
+// not belong to one block: g depends on l and the text only).  g0 receives seg * n_chains values in
+// step-major order, fillers (m + 1) in the tail of a short last chain.
+ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> &g0) {
+  if (ra < l.b || rb <= ra || rb > c.n)
+    fail(BWT_HIP_EINVAL, "chains: positions [%ld,%ld) are not to the right of block [%ld,%ld)", (long)ra, (long)rb,
+         (long)l.a, (long)l.b);
   build_wavelet(c, l);
-  const u64 m = (u64)l.len(), rn = (u64)r.len();
+  const u64 m = (u64)l.len(), rn = (u64)(rb - ra);
   if (m + rn >= (1ull << 32) - 2) fail(BWT_HIP_EINVAL, "merged block of %lu symbols exceeds 2^32-3", (unsigned long)(m + rn));
-  GapResult G;
+  ChainLayout lay;
   u64 seg = seg_req > 0 ? (u64)seg_req : 1024;
   if (seg > rn) seg = rn;
-  G.seg = (i64)seg;
-  G.n_chains = (i64)((rn + seg - 1) / seg);
-  const u64 total = seg * (u64)G.n_chains;
-  DBuf<u32> g0(c, total), g1(c, total);
+  lay.ra = (u64)ra;
+  lay.rb = (u64)rb;
+  lay.seg = (u32)seg;
+  lay.n_chains = (u32)((rn + seg - 1) / seg);
+  const u64 total = seg * (u64)lay.n_chains;
+  g0 = DBuf<u32>(c, total);
   ChainParams P;
   P.T = c.T;
   P.n = (u64)c.n;
-  P.ra = (u64)r.a;
-  P.rb = (u64)r.b;
+  P.ra = (u64)ra;
+  P.rb = (u64)rb;
   P.lb = (u64)l.b;
   P.m = (u32)m;
-  P.seg = (u32)seg;
-  P.n_chains = (u32)G.n_chains;
+  P.seg = lay.seg;
+  P.n_chains = lay.n_chains;
   // expected collapse after log_sigma(m) steps; sigma from the symbol width
   {
     double sig = (double)(c.max_sym < 2 ? 2 : c.max_sym);
@@ -275,38 +281,63 @@ GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
   {
     // 64-byte random reads: one rank block per level and step, one 16-byte text block every 16 steps
     Phase ph(c, "gap_chains", (double)rn * l.wm.levels + (double)rn / 16);
-    hipLaunchKernelGGL(k_chains, dim3(ceil_div(G.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
+    hipLaunchKernelGGL(k_chains, dim3(ceil_div(lay.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
   }
+  return lay;
+}
+
+void chains_text_order(Ctx &c, const ChainLayout &lay, const u32 *g0, u32 *out) {
+  hipLaunchKernelGGL(k_g_text_order, dim3(ceil_div(lay.rb - lay.ra, 256)), dim3(256), 0, c.stream, g0, lay.ra, lay.rb,
+                     lay.seg, lay.n_chains, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+// S[i] = #{ k : g[k] <= i } for i in [0, m], from `total` values g[k] in [0, m] (values above m are
+// ignored).  g0 holds the values and is destroyed; g1 is scratch of the same size.
+void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S) {
+  const int bits = bits_for(m + 1);
+  const int low = bits < GH_LOW_MAX ? bits : GH_LOW_MAX;
+  const int passes = (bits - low + 7) / 8;
+  Phase ph(c, "gap_histogram", (double)total * (passes * 12 + 4) + (double)(m + 1) * 4);
+  u32 *keys[2] = {g0, g1};
+  u32 *vals[2] = {nullptr, nullptr};
+  int cur = 0;
+  if (total > 0) {
+    c.sort_tag = "gap:";
+    cur = radix_sort_u32(c, keys, vals, total, low, bits, 2);
+    c.sort_tag = "";
+  }
+  const u32 n_buckets = (u32)(((m + 1) + ((u64)1 << low) - 1) >> low);
+  KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 4 + (double)(m + 1) * 4);
+  hipLaunchKernelGGL(k_bucket_prefix, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, keys[cur], (u32)total, low, (u32)m,
+                     S);
+  HIP_CHECK(hipGetLastError());
+}
+
+GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg_req, bool want_g) {
+  if (l.b != r.a) fail(BWT_HIP_EINVAL, "blocks are not adjacent: [%ld,%ld) and [%ld,%ld)", (long)l.a, (long)l.b,
+                       (long)r.a, (long)r.b);
+  const u64 m = (u64)l.len(), rn = (u64)r.len();
+  GapResult G;
+  DBuf<u32> g0;
+  ChainLayout lay = run_chains(c, l, r.a, r.b, seg_req, g0);
+  G.seg = lay.seg;
+  G.n_chains = lay.n_chains;
+  const u64 total = (u64)lay.seg * lay.n_chains;
+  DBuf<u32> g1(c, total);
   G.samp_g = DBuf<u32>(c, (size_t)(r.n_samp > 0 ? r.n_samp : 1));
   if (r.n_samp > 0) {
     hipLaunchKernelGGL(k_sample_g, dim3(ceil_div(r.n_samp, 256)), dim3(256), 0, c.stream, g0.get(), r.samp_pos.get(),
-                       (u32)r.n_samp, P.ra, P.rb, P.seg, P.n_chains, G.samp_g.get());
+                       (u32)r.n_samp, lay.ra, lay.rb, lay.seg, lay.n_chains, G.samp_g.get());
     HIP_CHECK(hipGetLastError());
   }
   if (want_g) {
     G.g_text = DBuf<u32>(c, rn);
-    hipLaunchKernelGGL(k_g_text_order, dim3(ceil_div(rn, 256)), dim3(256), 0, c.stream, g0.get(), P.ra, P.rb, P.seg,
-                       P.n_chains, G.g_text.get());
-    HIP_CHECK(hipGetLastError());
+    chains_text_order(c, lay, g0.get(), G.g_text.get());
   }
-  {
-    const int bits = bits_for(m + 1);
-    const int low = bits < GH_LOW_MAX ? bits : GH_LOW_MAX;
-    const int passes = (bits - low + 7) / 8;
-    Phase ph(c, "gap_histogram", (double)total * (passes * 12 + 4) + (double)(m + 1) * 4);
-    u32 *keys[2] = {g0.get(), g1.get()};
-    u32 *vals[2] = {nullptr, nullptr};
-    c.sort_tag = "gap:";
-    int cur = radix_sort_u32(c, keys, vals, total, low, bits, 2);
-    c.sort_tag = "";
-    G.S = DBuf<u32>(c, m + 1);
-    const u32 n_buckets = (u32)(((m + 1) + ((u64)1 << low) - 1) >> low);
-    KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 4 + (double)(m + 1) * 4);
-    hipLaunchKernelGGL(k_bucket_prefix, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, keys[cur], (u32)total, low,
-                       (u32)m, G.S.get());
-    HIP_CHECK(hipGetLastError());
-  }
+  G.S = DBuf<u32>(c, m + 1);
+  gap_prefix(c, g0.get(), g1.get(), total, m, G.S.get());
   return G;
 }
 

@@ -222,8 +222,35 @@ struct GapResult {
   i64 seg = 0, n_chains = 0;
 };
 GapResult build_gap(Ctx &c, Block &l, Block &r, i64 seg, bool want_g);
+// pieces of build_gap, used on their own when a merge is spread over several GPUs
+struct ChainLayout {
+  u64 ra, rb;  // right positions covered
+  u32 seg, n_chains;
+};
+ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg, DBuf<u32> &g0);
+void chains_text_order(Ctx &c, const ChainLayout &lay, const u32 *g0, u32 *out);
+void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S);
+void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 *S, u8 *out);
 // merge.hip
 Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
+
+// dist.hip: pieces of a merge spread over several GPUs
+void partition_bounds(u64 m, u32 parts, i64 *lo_out);
+void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host);
+struct ResamplePart {
+  const i64 *l_rank, *l_pos;
+  u64 nl;
+  const i64 *r_rank, *r_pos;
+  u64 nr;
+  i64 a, cc;           // first position of the left and of the right block
+  u64 A, B;            // ns_out - 1, nl + nr - 1
+  const u32 *S_local;  // S'[i - i_lo] for the left ranks i in [i_lo, i_hi): right suffixes of this part placed before i
+  u64 i_lo, i_hi, right_before;  // right_before: right suffixes in lower parts
+  const u32 *g_local;  // g_j for the positions j in [p_lo, p_hi), text order
+  u64 p_lo, p_hi;
+  i64 *o_rank, *o_pos;
+};
+void resample_part(Ctx &c, const ResamplePart &R);
 
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
 void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);

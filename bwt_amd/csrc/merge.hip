@@ -130,6 +130,16 @@ __global__ void k_resample(const u32 *__restrict__ l_rank, const u32 *__restrict
   o_pos[t0] = pos;
 }
 
+// out[0 : m + rn) = lL and rL interleaved as S says
+void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 *S, u8 *out) {
+  const u64 total = m + rn;
+  if (total == 0) return;
+  Phase ph(c, "merge_scatter", (double)total * 2 + (double)(m + 1) * 4);
+  hipLaunchKernelGGL(k_merge, dim3(ceil_div(total, MG_CHUNK)), dim3(MG_THREADS), 0, c.stream, lL, rL, S, (u32)m, total,
+                     out);
+  HIP_CHECK(hipGetLastError());
+}
+
 Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns_req) {
   const u64 m = (u64)l.len(), rn = (u64)r.len();
   const u64 total = m + rn;
@@ -139,12 +149,7 @@ Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns_req) {
     blk->b = r.b;
     blk->e_char = r.e_char;
     blk->L = DBuf<u8>(c, total);
-    {
-      Phase ph(c, "merge_scatter", (double)total * 2 + (double)(m + 1) * 4);
-      hipLaunchKernelGGL(k_merge, dim3(ceil_div(total, MG_CHUNK)), dim3(MG_THREADS), 0, c.stream, l.L.get(),
-                         r.L.get(), gap.S.get(), (u32)m, total, blk->L.get());
-      HIP_CHECK(hipGetLastError());
-    }
+    merge_symbols(c, l.L.get(), m, r.L.get(), rn, gap.S.get(), blk->L.get());
     // samples
     i64 ns = ns_req < (i64)total ? ns_req : (i64)total;  // include/bwt.h:840
     const u64 nn = (u64)(l.n_samp + r.n_samp);

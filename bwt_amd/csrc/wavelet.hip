@@ -43,6 +43,63 @@ __global__ void __launch_bounds__(HIST_THREADS)
   partial[(u64)blockIdx.x * 256 + tid] = tot;
 }
 
+// The same for a text with at most 7 distinct non-zero symbols (DNA): LDS counters would serialise on
+// the few addresses, so every thread counts in registers instead.  A symbol's code (0 for the
+// terminator, c - min_sym + 1 otherwise) selects one byte of a 64-bit accumulator, which is spilled
+// into eight 32-bit counters before a byte can overflow.
+__global__ void __launch_bounds__(HIST_THREADS)
+    k_sym_hist_small(const u8 *__restrict__ L, u64 m, u32 min_sym, u32 *__restrict__ partial) {
+  __shared__ u32 h[HIST_THREADS / 64][8];
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 acc = 0;
+  u32 pending = 0;
+  auto add = [&](u32 c) {
+    u32 code = c ? c - min_sym + 1 : 0u;
+    acc += 1ull << (8 * code);
+  };
+  auto spill = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; k++) cnt[k] += (u32)(acc >> (8 * k)) & 255u;
+    acc = 0;
+    pending = 0;
+  };
+  const u64 n16 = m / 16;
+  const uint4 *L16 = reinterpret_cast<const uint4 *>(L);
+  for (u64 i = (u64)blockIdx.x * HIST_THREADS + tid; i < n16; i += (u64)gridDim.x * HIST_THREADS) {
+    uint4 v = L16[i];
+    u32 ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) add((ws[k] >> (8 * b)) & 255u);
+    }
+    pending += 16;
+    if (pending > 255 - 16) spill();
+  }
+  spill();
+  if (blockIdx.x == 0)
+    for (u64 i = n16 * 16 + tid; i < m; i += HIST_THREADS) {
+      add(L[i]);
+      spill();
+    }
+#pragma unroll
+  for (int k = 0; k < 8; k++) cnt[k] = wave_reduce_sum(cnt[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[w][k] = cnt[k];
+  }
+  __syncthreads();
+  u32 tot = 0;
+  // column `tid` of the partial table is symbol `tid`: code 0 -> symbol 0, code k -> symbol min_sym + k - 1
+  u32 code = tid == 0 ? 0u : (tid >= min_sym && tid - min_sym + 1 < 8 ? tid - min_sym + 1 : 8u);
+  if (code < 8) {
+#pragma unroll
+    for (int k = 0; k < HIST_THREADS / 64; k++) tot += h[k][code];
+  }
+  partial[(u64)blockIdx.x * 256 + tid] = tot;
+}
+
 __global__ void k_hist_reduce(const u32 *__restrict__ partial, u32 nblk, u64 *__restrict__ out) {
   u32 c = threadIdx.x;
   u64 s = 0;
@@ -58,7 +115,12 @@ void count_alphabets(Ctx &c, Block &blk) {
   if (nblk == 0) nblk = 1;
   DBuf<u32> partial(c, (size_t)nblk * 256);
   DBuf<u64> tot(c, 256);
-  hipLaunchKernelGGL(k_sym_hist, dim3(nblk), dim3(HIST_THREADS), 0, c.stream, blk.L.get(), m, partial.get());
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  if (c.max_sym >= (int)min_sym && c.max_sym - (int)min_sym + 1 < 8)
+    hipLaunchKernelGGL(k_sym_hist_small, dim3(nblk), dim3(HIST_THREADS), 0, c.stream, blk.L.get(), m, min_sym,
+                       partial.get());
+  else
+    hipLaunchKernelGGL(k_sym_hist, dim3(nblk), dim3(HIST_THREADS), 0, c.stream, blk.L.get(), m, partial.get());
   hipLaunchKernelGGL(k_hist_reduce, dim3(1), dim3(256), 0, c.stream, partial.get(), nblk, tot.get());
   HIP_CHECK(hipGetLastError());
   u64 h[256];

@@ -153,6 +153,43 @@ int bwt_hip_block_LF(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uin
 int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t build_gap_segment_sz,
                 int64_t *gap_out, int64_t *g_out);
 
+/* ---- one merge spread over several GPUs ---------------------------------- */
+/* The reference merges in one address space (include/bwt.h:791-847); these entry points are the same
+   steps -- build_gap's LF chains (:730-787), the gap prefix sums, the interleaving of the two blocks and
+   resample_sa (:366-453) -- cut so that G processes, one per GPU, each do a share and exchange data in
+   between (bwt_amd/multi_gpu.py drives them).  The merge of a left block of m suffixes and a right block is
+   cut by LEFT RANK into `parts` parts: part k owns the left ranks [lo[k], lo[k+1]) and the right suffixes
+   whose insertion point g falls there; its output is a contiguous slice of the merged block.
+   All *_dev pointers are device memory of the context's GPU. */
+
+/* lo[0..parts]: first left rank (equally: first g value) of every part; lo[parts] = m + 1. */
+int bwt_hip_dist_bounds(int64_t m, int parts, int64_t *lo);
+/* g_dev[j - ra] = number of suffixes of block l smaller than T[j:], for the positions j in [ra, rb), ra >= l.b
+   (the block needs L, s_rank, e_rank only: one imported with n_samples = 0 will do). */
+int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l, int64_t ra, int64_t rb, int64_t build_gap_segment_sz,
+                        uint32_t *g_dev);
+/* Groups `count` g values by part: out_dev holds part 0's values, then part 1's, ... (any order inside a
+   part), each minus lo[part]; counts[k] = size of part k. */
+int bwt_hip_dist_partition(bwt_hip_ctx *ctx, const uint32_t *g_dev, int64_t count, int64_t m, int parts,
+                           uint32_t *out_dev, int64_t *counts);
+/* One part: lL_dev = the part's mL left symbols (rank order), rL_dev = its rn right symbols (rank order),
+   g_dev = their rn insertion points relative to the part's first left rank, any order (destroyed).
+   out_dev[0 : mL+rn) = the part's slice of the merged block; S_dev[i] (mL+1 entries) = right symbols of
+   the part placed before its left symbol i. */
+int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
+                             uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev);
+/* This part's share of the merged block's samples.  Inputs: all samples of the left block [a,c) and of the
+   right block [c,b) (rank = block-relative rank + first position, sorted by position); S_dev of this part
+   with its left ranks [i_lo, i_hi) and the number of right suffixes in lower parts; g_dev (text order) for
+   the positions [p_lo, p_hi) whose chains this GPU ran.  Kept samples this GPU can place are written to
+   their slot of o_rank_dev / o_pos_dev (*kept entries; zero them first and add the arrays of all GPUs up).
+   With null output arrays only *kept is computed. */
+int bwt_hip_dist_resample(bwt_hip_ctx *ctx, const int64_t *l_rank_dev, const int64_t *l_pos_dev, int64_t nl,
+                          const int64_t *r_rank_dev, const int64_t *r_pos_dev, int64_t nr, int64_t a, int64_t c,
+                          int64_t ssa_n_samples_out, const uint32_t *S_dev, int64_t i_lo, int64_t i_hi,
+                          int64_t right_before, const uint32_t *g_dev, int64_t p_lo, int64_t p_hi,
+                          int64_t *o_rank_dev, int64_t *o_pos_dev, int64_t *kept);
+
 /* ---- observability ------------------------------------------------------- */
 
 /* level > 0 records a hipEvent pair around every phase on the context's stream. */

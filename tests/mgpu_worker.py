@@ -54,6 +54,101 @@ class OracleOps:
         return blk
 
 
+class NumpyDistOps:
+    """The interface of bwt_amd.dist_merge.HipDistOps on the CPU (tests only): leaves from the oracle, the per-part
+    steps of a distributed merge restated in numpy from their definitions (g from a global suffix array)."""
+
+    def __init__(self, T, opt, ns, seg, th):
+        import torch
+        from oracle import Oracle
+        self.torch, self.T, self.ns, self.seg = torch, T, ns, seg
+        self.base = OracleOps(T, opt)
+        self.base.th = th
+        n = len(T)
+        sa = Oracle.sa_range(T, 0, n)
+        self.rank_of = np.empty(n, dtype=np.int64)
+        self.rank_of[sa] = np.arange(n)
+
+    def empty(self, n, dtype):
+        return self.torch.zeros(int(n), dtype=dtype)
+
+    def local_block(self, a, b, th, me):
+        from bwt_amd.dist_merge import DistBlock
+        blk = self.base.rec(a, b, th)
+        r, p = blk.samples()
+        t = self.torch
+        return DistBlock(a, b, [me], [b - a], t.from_numpy(self.base.L[a:b].copy()), blk.s_rank, blk.e_rank,
+                         t.from_numpy(r), t.from_numpy(p))
+
+    def left_block(self, a, c, L, s_rank, e_rank):
+        return (a, c)
+
+    def free_block(self, lb):
+        pass
+
+    def chains(self, lb, p_lo, p_hi):
+        a, c = lb
+        left = np.sort(self.rank_of[a:c])
+        g = np.searchsorted(left, self.rank_of[p_lo:p_hi]).astype(np.uint32)
+        return self.torch.from_numpy(g.view(np.int32).copy())
+
+    @staticmethod
+    def bounds(m, parts):
+        scale = (parts << 32) // (m + 1)
+        return [((k << 32) + scale - 1) // scale for k in range(parts)] + [m + 1], scale
+
+    def partition(self, g, m, parts):
+        lo, scale = self.bounds(m, parts)
+        v = g.numpy().view(np.uint32).astype(np.uint64)
+        part = ((v * np.uint64(scale)) >> np.uint64(32)).astype(np.int64)
+        order = np.argsort(part, kind="stable")[::-1].copy()   # any order inside a part is allowed: use a reversed one
+        order = order[np.argsort(part[order], kind="stable")]
+        out = (v[order] - np.array(lo, dtype=np.uint64)[part[order]]).astype(np.uint32)
+        counts = np.bincount(part, minlength=parts)
+        return self.torch.from_numpy(out.view(np.int32).copy()), [int(x) for x in counts]
+
+    def merge_slice(self, lL, rL, g_rel):
+        mL, rn = int(lL.numel()), int(rL.numel())
+        g = g_rel.numpy().view(np.uint32).astype(np.int64)
+        S = np.cumsum(np.bincount(g, minlength=mL + 1))[:mL + 1]
+        out = np.zeros(mL + rn, dtype=np.uint8)
+        is_left = np.zeros(mL + rn, dtype=bool)
+        where = np.arange(mL) + S[:mL]
+        is_left[where] = True
+        out[where] = lL.numpy()
+        out[~is_left] = rL.numpy()
+        return self.torch.from_numpy(out), self.torch.from_numpy(S.astype(np.uint32).view(np.int32).copy())
+
+    def resample(self, l_rank, l_pos, r_rank, r_pos, a, c, ns_out, S, i_lo, i_hi, right_before, g, p_lo, p_hi):
+        nl, nr = int(l_rank.numel()), int(r_rank.numel())
+        nn = nl + nr
+        A, B = ns_out - 1, nn - 1
+
+        def taken(i):  # include/bwt.h:412, :436 in closed form
+            if i == 0:
+                return 0
+            if B == 0:
+                return 1
+            return min(i, 1 + ((i - 1) * A) // B)
+        kept = min(nn, 1 + ((nn - 1) * A) // B if B else 1) if nn else 0
+        o_rank, o_pos = np.zeros(kept, dtype=np.int64), np.zeros(kept, dtype=np.int64)
+        Sn = S.numpy().view(np.uint32).astype(np.int64)
+        gn = g.numpy().view(np.uint32).astype(np.int64)
+        for i in range(nn):
+            t0, t1 = taken(i), taken(i + 1)
+            if t1 == t0:
+                continue
+            if i < nl:
+                rk = int(l_rank[i]) - a
+                if i_lo <= rk < i_hi:
+                    o_rank[t0], o_pos[t0] = a + rk + right_before + Sn[rk - i_lo], int(l_pos[i])
+            else:
+                p = int(r_pos[i - nl])
+                if p_lo <= p < p_hi:
+                    o_rank[t0], o_pos[t0] = a + int(r_rank[i - nl]) - c + gn[p - p_lo], p
+        return self.torch.from_numpy(o_rank), self.torch.from_numpy(o_pos)
+
+
 def export_import_check():
     """Single process: a block goes out through torch device tensors and comes back; merge results must not change.
     torch is imported before the HIP library is loaded, so both use the one HIP runtime torch ships."""
@@ -89,6 +184,7 @@ def main():
         return export_import_check()
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", default="hip")
+    ap.add_argument("--algo", default="tree", help="tree: blocks move to the left owner; dist: every merge on all GPUs of its subtree")
     ap.add_argument("--text_len", dest="n", type=int, default=100000)
     ap.add_argument("--sigma", type=int, default=4)
     ap.add_argument("--lpr", type=int, default=2)
@@ -102,6 +198,30 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     T = gen_text(args.n, 42, args.sigma)
+    if args.algo == "dist":
+        from bwt_amd import dist_merge
+        th = multi_gpu.leaf_threshold(args.n, world * args.lpr)
+        if args.ops == "hip":
+            import torch
+            import bwt_amd
+            dev = torch.device("cuda", 0)
+            ctx = bwt_amd.Context(0)
+            ctx.set_text(T)
+            ops = dist_merge.HipDistOps(ctx, args.ns, args.seg, dev)
+        else:
+            from oracle import Oracle
+            dev = "cpu"
+            opt = Oracle.opt(args.n, alpha_min=1, alpha_max=args.sigma, ssa_n_samples=args.ns, build_gap_segment_sz=args.seg)
+            ops = NumpyDistOps(T, opt, args.ns, args.seg, th)
+        groups = dist_merge.make_groups(dist, world)
+        blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, True)
+        L = dist_merge.gather_L(blk, rank, world, dist, dev, True)
+        if rank == 0:
+            np.savez(args.out, L=L, rank=blk.samp_rank.cpu().numpy(), pos=blk.samp_pos.cpu().numpy(), s_rank=blk.s_rank,
+                     e_rank=blk.e_rank, sizes=np.array(blk.sizes))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.ops == "hip":
         import bwt_amd
         ctx = bwt_amd.Context(0)

@@ -39,3 +39,24 @@ def test_two_rank_tree_equals_single_process(ctx, tmp_path, world, lpr):
     assert (int(res["s_rank"]), int(res["e_rank"])) == (ref.s_rank, ref.e_rank)
     r, p = ref.samples()
     assert (res["rank"] == r).all() and (res["pos"] == p).all()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,lpr,n,sigma", [(2, 1, 400000, 4), (4, 1, 400000, 4), (4, 2, 300001, 4), (8, 1, 250000, 4),
+                                               (4, 1, 200000, 255), (2, 1, 3000, 4)])
+def test_distributed_merge_equals_single_process(ctx, tmp_path, world, lpr, n, sigma):
+    """Every merge spread over all ranks of its subtree through the bwt_hip_dist_* entry points (all ranks on GPU 0,
+    exchange over gloo with host staging): same L, special ranks and samples as the single-process build."""
+    from bwt_amd import multi_gpu
+    ns = max(50, n // 200)
+    out = str(tmp_path / "res.npz")
+    _launch(world, ["--ops", "hip", "--algo", "dist", "--text_len", str(n), "--sigma", str(sigma), "--lpr", str(lpr),
+                    "--ns", str(ns)], out, timeout=800)
+    res = np.load(out)
+    ctx.set_text(gen_text(n, 42, sigma))
+    ref = ctx.pmbwt(multi_gpu.leaf_threshold(n, world * lpr), ns)
+    assert (res["L"] == ref.L).all()
+    assert (int(res["s_rank"]), int(res["e_rank"])) == (ref.s_rank, ref.e_rank)
+    r, p = ref.samples()
+    assert (res["rank"] == r).all() and (res["pos"] == p).all()
+    assert int(res["sizes"].sum()) == n and len(res["sizes"]) == world

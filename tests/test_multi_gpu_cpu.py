@@ -60,3 +60,38 @@ def test_gloo_tree_with_oracle_blocks(tmp_path, world, lpr):
     assert (int(res["s_rank"]), int(res["e_rank"])) == (ob.s_rank, ob.e_rank)
     r, p = ob.samples()
     assert (res["rank"] == r).all() and (res["pos"] == p).all()
+
+
+def test_dist_bounds_partition_the_left_ranks():
+    """bwt_hip_dist_bounds is host arithmetic (the library loads without a GPU): parts are contiguous, cover [0, m]
+    and agree with part(v) = (v * scale) >> 32."""
+    import bwt_amd
+    for m, parts in [(0, 2), (1, 2), (5, 8), (1000, 2), (12345, 8), (387500000, 8), (1550000000, 8), (2 ** 32 - 5, 4)]:
+        lo = [int(x) for x in bwt_amd.dist_bounds(m, parts)]
+        scale = (parts << 32) // (m + 1)
+        assert lo[0] == 0 and lo[-1] == m + 1 and all(x <= y for x, y in zip(lo, lo[1:]))
+        for k in range(1, parts):
+            v = lo[k]
+            if v <= m:
+                assert (v * scale) >> 32 >= k and ((v - 1) * scale) >> 32 < k
+        assert (m * scale) >> 32 < parts
+
+
+@pytest.mark.parametrize("world,lpr", [(2, 1), (4, 1), (4, 2), (8, 1)])
+def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr):
+    """Every merge spread over all ranks of its subtree (bwt_amd/dist_merge.py), the per-part steps done in numpy:
+    the exchange pattern and the bookkeeping are what is tested; the result must be the block of the same tree."""
+    n, ns, seg = 24000, 300, 64
+    out = str(tmp_path / "res.npz")
+    _launch(world, ["--ops", "oracle", "--algo", "dist", "--text_len", str(n), "--lpr", str(lpr), "--ns", str(ns),
+                    "--seg", str(seg)], out)
+    res = np.load(out)
+    T = gen_text(n, 42, 4)
+    th = multi_gpu.leaf_threshold(n, world * lpr)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=4, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (res["L"] == ob.L).all()
+    assert (int(res["s_rank"]), int(res["e_rank"])) == (ob.s_rank, ob.e_rank)
+    r, p = ob.samples()
+    assert (res["rank"] == r).all() and (res["pos"] == p).all()
+    assert int(res["sizes"].sum()) == n and len(res["sizes"]) == world
