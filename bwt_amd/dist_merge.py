@@ -83,14 +83,14 @@ class Comm:
                 w = self._wire(pieces[j]).contiguous()
                 for peer in self.ranks:
                     if peer != self.me:
-                        ops.append(self.dist.P2POp(self.dist.isend, w, peer))
+                        ops.append(self.dist.P2POp(self.dist.isend, w, peer, group=self.group))
             else:
                 if self.host_staging:
                     buf = torch.empty(hi - lo, dtype=out.dtype)
                     stage.append((lo, hi, buf))
                 else:
                     buf = out[lo:hi]
-                ops.append(self.dist.P2POp(self.dist.irecv, buf, owner))
+                ops.append(self.dist.P2POp(self.dist.irecv, buf, owner, group=self.group))
         if ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()

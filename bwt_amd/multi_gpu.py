@@ -147,12 +147,32 @@ def bench_main(args, rank, local_rank, world):
     total_leaves = world * lpr
     depth = total_leaves.bit_length() - 1
     ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
-    ops = HipOps(ctx, ns, args.seg, True, dev)
+    # "dist" (default): every merge runs on all GPUs of its subtree and the result stays spread over the GPUs
+    # (bwt_amd/dist_merge.py); "tree": right blocks move to the left owner, the result ends on rank 0
+    algo = os.environ.get("BWT_MGPU_ALGO", "dist")
+    if algo == "dist":
+        from bwt_amd import dist_merge
+        dops = dist_merge.HipDistOps(ctx, ns, args.seg, dev)
+        groups = dist_merge.make_groups(dist, world)
 
-    def step():
-        blk = pmbwt_tree(ops, rank, world, n, lpr, dist, hdr_device=dev)
-        ctx.sync()
-        return blk
+        class _Held:  # what a step leaves behind: this rank's slice (torch frees it with the object)
+            def __init__(self, d):
+                self.d = d
+
+            def free(self):
+                self.d = None
+
+        def step():
+            d = dist_merge.pmbwt_dist(dops, rank, world, n, lpr, dist, groups, dev, False)
+            ctx.sync()
+            return _Held(d)
+    else:
+        ops = HipOps(ctx, ns, args.seg, True, dev)
+
+        def step():
+            blk = pmbwt_tree(ops, rank, world, n, lpr, dist, hdr_device=dev)
+            ctx.sync()
+            return blk
 
     for _ in range(args.warmup):
         blk = step()
@@ -185,11 +205,14 @@ def bench_main(args, rank, local_rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
-            "config": {"workload": "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0"
+            "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
+                                    "subtree (RCCL point-to-point + all-to-all); L stays sliced over the GPUs, samples on rank 0"
+                                    if algo == "dist" else
+                                    "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0")
                                    % (n, total_leaves, world),
                        "n": n, "sigma": args.sigma, "leaves": total_leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                        "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True,
-                       "parallelism": "leaf-sharded x%d, pairwise merge tree" % world},
+                       "parallelism": "leaf-sharded x%d, %s" % (world, "distributed merges" if algo == "dist" else "pairwise merge tree")},
             # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
             "roofline": roofline(timers), "cpu_baseline": None,
             "phases_rank0": phase_table(timers, args.steps),

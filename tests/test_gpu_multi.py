@@ -43,7 +43,7 @@ def test_two_rank_tree_equals_single_process(ctx, tmp_path, world, lpr):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,lpr,n,sigma", [(2, 1, 400000, 4), (4, 1, 400000, 4), (4, 2, 300001, 4), (8, 1, 250000, 4),
-                                               (4, 1, 200000, 255), (2, 1, 3000, 4)])
+                                               (4, 1, 200000, 255), (2, 1, 3000, 4), (4, 1, 20000000, 4)])
 def test_distributed_merge_equals_single_process(ctx, tmp_path, world, lpr, n, sigma):
     """Every merge spread over all ranks of its subtree through the bwt_hip_dist_* entry points (all ranks on GPU 0,
     exchange over gloo with host staging): same L, special ranks and samples as the single-process build."""
