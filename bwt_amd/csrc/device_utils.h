@@ -97,6 +97,16 @@ __device__ __forceinline__ void match_digit8(u32 digit, u32 &lo, u32 &hi) {
   }
 }
 
+// floor(x / d) for d > 0.  64-bit integer division is a long instruction sequence on the GPU; below 2^53 a
+// double division is off by at most one, which two multiplications put right.
+__device__ __forceinline__ u64 div_floor_u64(u64 x, u64 d) {
+  if (x >= (1ull << 53) || d >= (1ull << 53)) return x / d;
+  u64 q = (u64)((double)x / (double)d);
+  if (q * d > x) q--;
+  else if ((q + 1) * d <= x) q++;
+  return q;
+}
+
 // number of set bits of (hi:lo) below this lane
 __device__ __forceinline__ u32 count_below_lane(u32 lo, u32 hi) {
   return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));

@@ -122,7 +122,7 @@ void partition_bounds(u64 m, u32 parts, i64 *lo_out) {
 __device__ __forceinline__ u64 taken_before_d(u64 i, u64 A, u64 B) {
   if (i == 0) return 0;
   if (B == 0) return 1;
-  u64 t = 1 + ((i - 1) * A) / B;
+  u64 t = 1 + div_floor_u64((i - 1) * A, B);
   return t < i ? t : i;
 }
 
