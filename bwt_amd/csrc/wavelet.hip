@@ -100,11 +100,23 @@ __global__ void __launch_bounds__(HIST_THREADS)
   partial[(u64)blockIdx.x * 256 + tid] = tot;
 }
 
-__global__ void k_hist_reduce(const u32 *__restrict__ partial, u32 nblk, u64 *__restrict__ out) {
-  u32 c = threadIdx.x;
+// column sums of the [workgroup][256] table: 1024 threads, four row groups, rows eight at a time
+__global__ void __launch_bounds__(1024) k_hist_reduce(const u32 *__restrict__ partial, u32 nblk, u64 *__restrict__ out) {
+  __shared__ u64 part[4][256];
+  const u32 c = threadIdx.x & 255, grp = threadIdx.x >> 8;
   u64 s = 0;
-  for (u32 b = 0; b < nblk; b++) s += partial[(u64)b * 256 + c];
-  out[c] = s;
+  u32 b = grp;
+  for (; b + 28 < nblk; b += 32) {
+    u32 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = partial[(u64)(b + 4 * k) * 256 + c];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[k];
+  }
+  for (; b < nblk; b += 4) s += partial[(u64)b * 256 + c];
+  part[grp][c] = s;
+  __syncthreads();
+  if (grp == 0) out[c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
 void count_alphabets(Ctx &c, Block &blk) {
@@ -121,7 +133,7 @@ void count_alphabets(Ctx &c, Block &blk) {
                        partial.get());
   else
     hipLaunchKernelGGL(k_sym_hist, dim3(nblk), dim3(HIST_THREADS), 0, c.stream, blk.L.get(), m, partial.get());
-  hipLaunchKernelGGL(k_hist_reduce, dim3(1), dim3(256), 0, c.stream, partial.get(), nblk, tot.get());
+  hipLaunchKernelGGL(k_hist_reduce, dim3(1), dim3(1024), 0, c.stream, partial.get(), nblk, tot.get());
   HIP_CHECK(hipGetLastError());
   u64 h[256];
   u8 hidden = 0;
@@ -169,14 +181,27 @@ __global__ void __launch_bounds__(WM_THREADS)
     k_wm_plane(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u32 min_sym, int raw,
                u64 *__restrict__ plane, u32 *__restrict__ tile_cnt, u32 tiles) {
   __shared__ u32 wc[WM_THREADS / 64][4];
+  __shared__ __align__(16) u8 stage[WM_TILE];  // the tile's symbols: 16-byte global loads, byte reads from LDS
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 tile0 = blockIdx.x * WM_TILE;
+  static_assert(WM_TILE % 16 == 0 && WM_TILE / 16 <= WM_THREADS, "one 16-byte load per thread covers the tile");
+  if (tid < WM_TILE / 16) {
+    const u32 g0 = tile0 + tid * 16;  // tile0 is a multiple of 16 and `cur` is 256-byte aligned
+    if (g0 + 16 <= m) {
+      reinterpret_cast<uint4 *>(stage)[tid] = *reinterpret_cast<const uint4 *>(cur + g0);
+    } else {
+      for (u32 k = 0; k < 16; k++) stage[tid * 16 + k] = g0 + k < m ? cur[g0 + k] : (u8)0;
+    }
+  }
+  __syncthreads();
   u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
   for (int r = 0; r < WM_ROUNDS; r++) {
     u32 wi = r * (WM_THREADS / 64) + w;
     u32 idx = tile0 + wi * 64 + lane;
-    u32 d = (wm_code(cur, idx, m, hidden, min_sym, raw) >> shift) & 3;
+    u32 ch = stage[wi * 64 + lane];  // zero beyond m
+    u32 code = (!raw) ? ch : ((idx == hidden || ch < min_sym) ? 0u : ch - min_sym);
+    u32 d = (idx < m ? code >> shift : 0u) & 3;
     u64 b0 = __ballot(d & 1), b1 = __ballot(d >> 1), v = __ballot(idx < m);
     c0 += __popcll(~b1 & ~b0 & v);
     c1 += __popcll(~b1 & b0 & v);
