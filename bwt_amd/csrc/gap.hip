@@ -183,15 +183,19 @@ __device__ __forceinline__ u32 wave_bucket_start(const u32 *__restrict__ keys, u
   }
 }
 
+// LDS counter v lives at word v + v/32: a thread's 32 consecutive counters then start 33 words apart
+// from its neighbour's, so the per-thread sequential scan below is free of bank conflicts.
+__device__ __forceinline__ u32 gh_slot(u32 v) { return v + (v >> 5); }
+
 __global__ void __launch_bounds__(GH_THREADS)
     k_bucket_prefix(const u32 *__restrict__ keys, u32 total, int low, u32 m, u32 *__restrict__ S) {
-  __shared__ u32 hist[1 << GH_LOW_MAX];
+  __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
   __shared__ u32 bounds[2];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
   const u32 width = 1u << low;
   const u32 bucket = blockIdx.x;
-  for (u32 i = tid; i < width; i += GH_THREADS) hist[i] = 0;
+  for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
   if (tid < 128) {
     u32 v = wave_bucket_start(keys, total, low, bucket + (tid >> 6));
     if ((tid & 63) == 0) bounds[tid >> 6] = v;
@@ -208,24 +212,24 @@ __global__ void __launch_bounds__(GH_THREADS)
     }
 #pragma unroll
     for (int k = 0; k < 8; k++)
-      if (g[k] <= m) atomicAdd(&hist[g[k] & (width - 1)], 1u);  // LDS counter; fillers (m+1) are skipped
+      if (g[k] <= m) atomicAdd(&hist[gh_slot(g[k] & (width - 1))], 1u);  // LDS counter; fillers (m+1) are skipped
   }
   __syncthreads();
   // inclusive scan of the counters: each thread owns width/256 consecutive ones
   const u32 per = (width + GH_THREADS - 1) / GH_THREADS;
   const u32 j0 = tid * per;
   u32 mine = 0;
-  for (u32 j = j0; j < j0 + per && j < width; j++) mine += hist[j];
+  for (u32 j = j0; j < j0 + per && j < width; j++) mine += hist[gh_slot(j)];
   u32 all;
   u32 run = lo + block_scan_incl<OpSum>(mine, scan_s, &all) - mine;
   for (u32 j = j0; j < j0 + per && j < width; j++) {
-    run += hist[j];
-    hist[j] = run;
+    run += hist[gh_slot(j)];
+    hist[gh_slot(j)] = run;
   }
   __syncthreads();
   const u64 base = (u64)bucket << low;
   for (u32 j = tid; j < width; j += GH_THREADS)
-    if (base + j <= m) S[base + j] = hist[j];
+    if (base + j <= m) S[base + j] = hist[gh_slot(j)];
 }
 
 static int bits_for(u64 x) {

@@ -16,9 +16,27 @@ constexpr int MG_PER_THREAD = 16;
 constexpr int MG_CHUNK = MG_THREADS * MG_PER_THREAD;  // 4096 output bytes per workgroup
 
 // Number of i in [0, m) with i + S[i] < P; all 64 lanes cooperate (64-ary search).
-__device__ __forceinline__ u32 wave_count_below(const u32 *__restrict__ S, u32 m, u64 P) {
+// The first round probes around the position a uniform interleaving would give (left_share = m / total), which
+// on most inputs leaves a range of a few hundred candidates instead of m.
+__device__ __forceinline__ u32 wave_count_below(const u32 *__restrict__ S, u32 m, u64 P, float left_share) {
   u32 lo = 0, hi = m;  // answer in [lo, hi]
   const u32 lane = lane_id();
+  if (m > 64 * 1024) {
+    constexpr long long W = 512;
+    long long est = (long long)((double)P * (double)left_share);
+    long long idx = est + ((long long)lane - 32) * W;
+    bool t = idx < 0 || (idx < (long long)m && (u64)idx + S[idx] < P);
+    u32 cnt = (u32)__popcll(__ballot(t));
+    long long first = est - 32 * W;  // probe of lane 0
+    if (cnt > 0) {
+      long long l = first + (long long)(cnt - 1) * W + 1;  // one past the last probe that is below P
+      lo = l < 0 ? 0u : (l > (long long)m ? m : (u32)l);
+    }
+    if (cnt < 64) {
+      long long h = first + (long long)cnt * W;  // the first probe that is not below P
+      hi = h < 0 ? 0u : (h > (long long)m ? m : (u32)h);
+    }
+  }
   for (;;) {
     u32 span = hi - lo;
     if (span <= 64) {
@@ -41,7 +59,7 @@ __device__ __forceinline__ u32 wave_count_below(const u32 *__restrict__ S, u32 m
 
 __global__ void __launch_bounds__(MG_THREADS)
     k_merge(const u8 *__restrict__ lL, const u8 *__restrict__ rL, const u32 *__restrict__ S, u32 m, u64 total,
-            u8 *__restrict__ out) {
+            float left_share, u8 *__restrict__ out) {
   __shared__ u8 is_left[MG_CHUNK];
   __shared__ u32 bounds[2];
   __shared__ u32 scan_s[17];
@@ -50,7 +68,7 @@ __global__ void __launch_bounds__(MG_THREADS)
   const u64 p1 = (p0 + MG_CHUNK < total) ? p0 + MG_CHUNK : total;
   reinterpret_cast<uint4 *>(is_left)[tid] = make_uint4(0, 0, 0, 0);
   if (tid < 128) {  // waves 0 and 1: left symbols placed before p0, before p1
-    u32 v = wave_count_below(S, m, (tid < 64) ? p0 : p1);
+    u32 v = wave_count_below(S, m, (tid < 64) ? p0 : p1, left_share);
     if ((tid & 63) == 0) bounds[tid >> 6] = v;
   }
   __syncthreads();
@@ -136,7 +154,7 @@ void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 
   if (total == 0) return;
   Phase ph(c, "merge_scatter", (double)total * 2 + (double)(m + 1) * 4);
   hipLaunchKernelGGL(k_merge, dim3(ceil_div(total, MG_CHUNK)), dim3(MG_THREADS), 0, c.stream, lL, rL, S, (u32)m, total,
-                     out);
+                     (float)((double)m / (double)total), out);
   HIP_CHECK(hipGetLastError());
 }
 
