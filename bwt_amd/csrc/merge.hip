@@ -57,10 +57,22 @@ __device__ __forceinline__ u32 wave_count_below(const u32 *__restrict__ S, u32 m
   }
 }
 
+// aligned 16-byte loads of src[first : first + count) into LDS; returns where src[first] sits in `dst`
+__device__ __forceinline__ u32 stage_bytes(u8 *dst, const u8 *__restrict__ src, u64 first, u32 count, u32 tid) {
+  const uintptr_t ad = reinterpret_cast<uintptr_t>(src + first);
+  const u32 off = (u32)(ad & 15);
+  if (count == 0) return off;
+  const uint4 *base = reinterpret_cast<const uint4 *>(ad - off);
+  const u32 words = (off + count + 15) / 16;  // <= MG_CHUNK / 16 + 1
+  for (u32 q = tid; q < words; q += MG_THREADS) reinterpret_cast<uint4 *>(dst)[q] = base[q];
+  return off;
+}
+
 __global__ void __launch_bounds__(MG_THREADS)
     k_merge(const u8 *__restrict__ lL, const u8 *__restrict__ rL, const u32 *__restrict__ S, u32 m, u64 total,
             float left_share, u8 *__restrict__ out) {
   __shared__ u8 is_left[MG_CHUNK];
+  __shared__ __align__(16) u8 src_l[MG_CHUNK + 32], src_r[MG_CHUNK + 32];  // the chunk's left and right symbols
   __shared__ u32 bounds[2];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
@@ -74,6 +86,11 @@ __global__ void __launch_bounds__(MG_THREADS)
   __syncthreads();
   const u32 tlo = bounds[0], thi = bounds[1];
   for (u32 t = tlo + tid; t < thi; t += MG_THREADS) is_left[(u64)t + S[t] - p0] = 1;
+  // An aligned 16-byte block never straddles a page, so reading the whole block of a valid byte is safe.
+  const u32 n_left = thi - tlo, n_right = (u32)(p1 - p0) - n_left;
+  const u64 r0 = p0 - tlo;  // right symbols placed before p0
+  const u32 off_l = stage_bytes(src_l, lL, tlo, n_left, tid);
+  const u32 off_r = stage_bytes(src_r, rL, r0, n_right, tid);
   __syncthreads();
   const u32 q0 = tid * MG_PER_THREAD;
   uint4 fl = reinterpret_cast<const uint4 *>(is_left)[tid];
@@ -81,8 +98,8 @@ __global__ void __launch_bounds__(MG_THREADS)
   u32 mine = __popc(fw[0]) + __popc(fw[1]) + __popc(fw[2]) + __popc(fw[3]);  // flags are 0/1 bytes
   u32 all;
   u32 incl = block_scan_incl<OpSum>(mine, scan_s, &all);
-  u64 li = (u64)tlo + (incl - mine);  // next left symbol
-  u64 ri = p0 + q0 - li;              // next right symbol
+  u32 li = off_l + (incl - mine);        // next left symbol, in src_l
+  u32 ri = off_r + q0 - (incl - mine);   // next right symbol, in src_r
   if (p0 + q0 >= p1) return;
   u32 ow[4];
 #pragma unroll
@@ -93,13 +110,8 @@ __global__ void __launch_bounds__(MG_THREADS)
       u64 p = p0 + q0 + k * 4 + b;
       u32 ch = 0;
       if (p < p1) {
-        if ((fw[k] >> (8 * b)) & 1) {
-          if (li < m) ch = lL[li];
-          li++;
-        } else {
-          if (ri < total - m) ch = rL[ri];
-          ri++;
-        }
+        if ((fw[k] >> (8 * b)) & 1) ch = src_l[li++];
+        else ch = src_r[ri++];
       }
       word |= ch << (8 * b);
     }
