@@ -182,6 +182,14 @@ __device__ __forceinline__ u32 digit_of(K key, int shift, u32 mask) {
   return (u32)(key >> shift) & mask;
 }
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding
+// global access of the wave).  Tried on top of it and dropped: a persistent variant that loops over tiles
+// and issues the next tile's loads while the current one is written out -- 80 registers do not hold both
+// tiles' state (spills), and at 2 workgroups per CU it was 50 % slower than one tile per workgroup.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Ranking, ordering in LDS and writing of one tile.  FULL: the tile has all RS_TILE keys.
 template <class K, bool HAS_VALS, bool FULL, bool SPLIT>
 __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
@@ -220,7 +228,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     rk[r] = base + before;
   }
-  __syncthreads();
+  lds_barrier();
   {
     // thread d < 256 owns digit d: wave counts -> wave offsets, digit totals -> tile-local digit starts
     u32 tot = 0;
@@ -232,18 +240,21 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
         tot += v;
       }
     }
-    u32 all;
-    u32 incl = block_scan_incl<OpSum>(tot, scan_s, &all);
+    // exclusive scan of the 256 digit totals: they sit in the first four waves
+    u32 incl = wave_scan_incl_sum(tot);
+    if (lane == 63 && w < 4) scan_s[w] = incl;
+    lds_barrier();
+    for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
     if (tid < 256) {
       u32 ds = incl - tot;
       dstart[tid] = ds;
       gbase[tid] = offs[(size_t)tid * nblk + tile] - ds;
     }
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) rk[r] += dstart[dig[r]] + myc[dig[r]];  // position inside the tile
-  __syncthreads();  // counters are dead from here: the buffer becomes the staging area
+  lds_barrier();  // counters are dead from here: the buffer becomes the staging area
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     if (FULL || wbase + r * 64 + lane < tile_n) {
@@ -251,7 +262,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       if (HAS_VALS) vals_s[rk[r]] = val[r];
     }
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const u32 p = r * RS_THREADS + tid;
@@ -326,13 +337,22 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     const u32 *lo = reinterpret_cast<const u32 *>(kin) + tile0;
     const u32 *hi = lo + stride;
     const u32 *vt = vin + tile0;
+    if (full) {  // no per-lane conditions: all loads are issued back to back
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-      u32 idx = wbase + r * 64 + lane;
-      bool valid = full || idx < tile_n;
-      u32 l = valid ? lo[idx] : 0u, h = valid ? hi[idx] : 0u;
-      key[r] = (K)(((u64)h << 32) | l);
-      if (HAS_VALS) val[r] = valid ? vt[idx] : 0u;
+      for (int r = 0; r < RS_ITEMS; r++) {
+        u32 idx = wbase + r * 64 + lane;
+        key[r] = (K)(((u64)hi[idx] << 32) | lo[idx]);
+        if (HAS_VALS) val[r] = vt[idx];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RS_ITEMS; r++) {
+        u32 idx = wbase + r * 64 + lane;
+        bool valid = idx < tile_n;
+        u32 l = valid ? lo[idx] : 0u, h = valid ? hi[idx] : 0u;
+        key[r] = (K)(((u64)h << 32) | l);
+        if (HAS_VALS) val[r] = valid ? vt[idx] : 0u;
+      }
     }
   } else {
     const K *kt = kin + tile0;      // uniform base + 32-bit lane offset
