@@ -272,7 +272,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       if constexpr (SPLIT) {
         u32 *klo = reinterpret_cast<u32 *>(kout);
         klo[dst] = (u32)k;
-        klo[stride + dst] = (u32)((u64)k >> 32);
+        klo[(size_t)stride + dst] = (u32)((u64)k >> 32);  // beyond 2^32 words for windows above 2^31
       } else {
         kout[dst] = k;
       }

@@ -104,3 +104,23 @@ def test_few_distinct_symbols_in_a_wide_alphabet(ctx):
     T = np.concatenate([rng.integers(97, 101, size=150000, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
     _same_as_oracle(ctx, T, 100, 20000, 500)
     _same_as_oracle(ctx, T, 100, 3000, 500, 64)
+
+
+@pytest.mark.timeout(600)
+def test_leaf_window_above_2_31(ctx):
+    """A single leaf of 2.3e9 suffixes (array indices beyond 2^31, split key halves beyond 2^32 words) gives the
+    same L as two leaves and a merge; both are permutations of the text's symbols."""
+    n = 2300000000
+    ctx.gen_text(n, 42, 4)
+    one = ctx.pmbwt(n, 100000)
+    L1 = one.L
+    one.free()
+    two = ctx.pmbwt(n // 2 + 1, 100000)
+    L2 = two.L
+    r, p = two.samples()
+    two.free()
+    assert L1.shape == (n,) and (L1 == L2).all()
+    counts = np.bincount(L1, minlength=5)
+    assert counts[0] == 1 and counts[1:5].sum() == n - 1 and abs(int(counts[1]) - n // 4) < 200000
+    T = ctx.get_text()
+    assert (L2[r] == T[p - 1]).all()  # L[rank] = T[pos-1] for every sample (index -1 is the last symbol, as it should be)
