@@ -245,17 +245,26 @@ def dist_merge(ops, comm, blk, ns_req):
     out, S = ops.merge_slice(fullL[i_lo:i_hi], rL, g_in)
     sizes = [min(lo[d + 1], m) - min(lo[d], m) + R[d] for d in range(G)]
 
-    # 5. samples: everybody learns both sample sets, places what it can, the first GPU adds up
-    l_rank, l_pos = (blk.samp_rank, blk.samp_pos) if me == root else (ops.empty(nl, torch.int64), ops.empty(nl, torch.int64))
-    r_rank, r_pos = (blk.samp_rank, blk.samp_pos) if me == rroot else (ops.empty(nr, torch.int64), ops.empty(nr, torch.int64))
-    for t in (l_rank, l_pos):
-        comm.broadcast(t, root)
-    for t in (r_rank, r_pos):
-        comm.broadcast(t, rroot)
+    # 5. samples: everybody learns both sample sets, places what it can, the first GPU adds up.  Ranks and positions
+    # are below 2^32, so they travel as 32-bit words (bit patterns in int32 tensors; adding zeros cannot carry).
+    def narrow(t):
+        return t.to(torch.int32)
+
+    def widen(t):
+        return t.to(torch.int64) & 0xFFFFFFFF
+
+    wire = []
+    for owner, cnt, src in ((root, nl, blk.samp_rank), (root, nl, blk.samp_pos), (rroot, nr, blk.samp_rank), (rroot, nr, blk.samp_pos)):
+        t = narrow(src) if me == owner else ops.empty(cnt, torch.int32)
+        comm.broadcast(t, owner)
+        wire.append(widen(t))
+    l_rank, l_pos, r_rank, r_pos = wire
     ns_out = min(ns_req, m + r)
     o_rank, o_pos = ops.resample(l_rank, l_pos, r_rank, r_pos, a, c, ns_out, S, i_lo, i_hi, rb[k], g, p_lo, p_hi)
+    o_rank, o_pos = narrow(o_rank), narrow(o_pos)
     comm.sum_to(o_rank, root)
     comm.sum_to(o_pos, root)
+    o_rank, o_pos = widen(o_rank), widen(o_pos)
     new = DistBlock(a, b, ranks, sizes, out)
     if me == root:
         first = [int(x) for x in o_rank[:1].cpu().tolist()] + [int(x) for x in o_rank[-1:].cpu().tolist()]
