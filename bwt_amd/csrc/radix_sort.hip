@@ -47,8 +47,8 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nblk) {
 
 // ----------------------------------------------------------------------------
 // keys rolled out of the text (first pass of the leaf suffix sort)
-//   key(i) = | K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
-//              left-aligned | zero padding | T[a+i-1] in the low w bits |
+//   key(i) = | codes of the K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
+//              left-aligned | end field | zero padding | T[a+i-1] in the low 8 bits |   (TextKeys in internal.h)
 //   value(i) = a + i
 // Positions >= n read as 0; T[-1] is T[n-1].
 // ----------------------------------------------------------------------------
@@ -81,29 +81,40 @@ __device__ __forceinline__ void tk_stage(u32 *S32, const TextKeys &tk, u64 tile0
 }
 
 // keys k0 .. k0+ITEMS-1 of the tile (k0 a multiple of 4), from the staged text
+// tile0 + k0 = window index of the first key
 template <int ITEMS>
-__device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
-  const int w = tk.w, K0 = tk.K0;
-  const int used = K0 * w;  // <= 64 - w
+__device__ __forceinline__ void tk_roll(const u32 *S32, u64 tile0, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
+  const int w = tk.w, K0 = tk.K0, fb = tk.fbits;
+  const int used = K0 * w;  // used + fb <= 56
   const u64 maskall = (1ull << used) - 1;
   const int lsh = 64 - used;
-  const u32 symmask = (1u << w) - 1;
+  const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
+  const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
   u64 sf = 0;
   u32 wd = 0;
   for (int k = 0; k < K0; k++) {
     if ((k & 3) == 0) wd = src[k >> 2];
-    sf = (sf << w) | (wd & 255u);
+    u32 ch = wd & 255u;
+    sf = (sf << w) | (ch ? ch - ms : 0u);
     wd >>= 8;
   }
-  u32 prev = reinterpret_cast<const u8 *>(S32)[TK_LEAD + k0 - 1];
+  // the first position whose K0 symbols reach the terminator (position n-1)
+  const long long pos0 = (long long)(tk.a + tile0 + k0);
+  const long long reach = (long long)tk.n - K0;
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    key_out[j] = (sf << lsh) | prev;
-    prev = (u32)(sf >> (used - w)) & symmask;
+    u64 key = (sf << lsh) | raw[j - 1];  // the preceding symbol as it is
+    if (fb) {
+      long long e = pos0 + j - reach + 1;  // of the K0 positions, those at or past the terminator
+      e = e < 0 ? 0 : (e > K0 ? K0 : e);
+      key |= (u64)(K0 - e) << (lsh - fb);
+    }
+    key_out[j] = key;
     const int k = K0 + j;
     if ((k & 3) == 0) wd = src[k >> 2];
-    sf = ((sf << w) | (wd & 255u)) & maskall;
+    u32 ch = wd & 255u;
+    sf = ((sf << w) | (ch ? ch - ms : 0u)) & maskall;
     wd >>= 8;
   }
 }
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(RH_THREADS)
     tk_stage(stage, tk, tile0, tid, RH_THREADS);
     __syncthreads();
     u64 key[RH_ITEMS];
-    tk_roll<RH_ITEMS>(stage, tid * RH_ITEMS, tk, key);
+    tk_roll<RH_ITEMS>(stage, tile0, tid * RH_ITEMS, tk, key);
 #pragma unroll
     for (int r = 0; r < RH_ITEMS; r++) {
       u32 d = (u32)(key[r] >> shift) & mask;
@@ -320,7 +331,7 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     tk_stage(stage, tk, tile0, tid, RS_THREADS);
     __syncthreads();
     u64 mine[RS_ITEMS];
-    tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
+    tk_roll<RS_ITEMS>(stage, tile0, tid * RS_ITEMS, tk, mine);
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) ex[tid * (RS_ITEMS + 1) + j] = mine[j];
     __syncthreads();

@@ -425,32 +425,56 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
   return b;
 }
 
-// How many symbols the round-0 key holds.  Every 8 key bits cost one radix pass
-// over the whole window; fewer symbols leave more suffixes tied for the
-// refinement rounds, which only touch the tied ones.  Take the fewest passes for
-// which a random text of this alphabet would leave under 2 % tied.
-static int choose_k0(int w, int max_sym, u64 N) {
-  const int kmax = 56 / w;  // the low 8 key bits hold the preceding symbol and are not sorted on
-  const double sigma = max_sym < 2 ? 2.0 : (double)max_sym;
-  for (int passes = 1; passes * 8 <= kmax * w + 7; passes++) {
-    int k = passes * 8 / w;
-    if (k > kmax) k = kmax;
-    if (k < 1) continue;
-    double distinct = 1;
-    for (int j = 0; j < k && distinct < 1e30; j++) distinct *= sigma;
-    if ((double)N / distinct <= 0.02) return k;
+// Layout of the round-0 key (TextKeys): coding, number of symbols K0.  Every 8 sorted key bits cost one radix
+// pass over the whole window; fewer symbols leave more suffixes tied for the refinement, which only touches
+// the tied ones.  Take the coding and the fewest passes for which a random text of this alphabet would leave
+// under 5 % tied (below that, ordering the ties by direct comparison is cheaper than another pass).
+struct KeyPlan {
+  int w, K0, one_based, fbits, passes;
+};
+
+static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
+  const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
+  KeyPlan best;
+  memset(&best, 0, sizeof(best));
+  double best_tied = 2.0;
+  for (int one_based = 1; one_based >= 0; one_based--) {
+    const int w = bits_for((u64)(span + one_based));
+    if (!one_based && w == bits_for((u64)(span + 1))) continue;  // no bit saved: keep the exact coding
+    for (int passes = 1; passes <= 7; passes++) {
+      // most symbols with K0*w + fbits <= 8*passes (and <= 56: the low byte is the preceding symbol)
+      int K0 = 0;
+      for (int k = 1; k * w <= 8 * passes; k++) {
+        int fb = one_based ? 0 : bits_for((u64)k);
+        if (k * w + fb <= 8 * passes) K0 = k;
+      }
+      if (K0 < 1) continue;
+      double distinct = 1;
+      for (int j = 0; j < K0 && distinct < 1e30; j++) distinct *= sigma;
+      const double tied = (double)N / distinct;
+      const bool good = tied <= 0.05;
+      const bool better = best.K0 == 0 || (good && (best_tied > 0.05 || passes < best.passes)) ||
+                          (!good && best_tied > 0.05 && tied < best_tied);
+      if (better) {
+        best = KeyPlan{w, K0, one_based, one_based ? 0 : bits_for((u64)K0), passes};
+        best_tied = tied;
+      }
+      if (good) break;  // more passes of this coding cannot be better
+    }
   }
-  return kmax;
+  return best;
 }
 
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
 static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_out) {
   const u64 N = (u64)(e - a);
-  const int w = c.sym_bits;
-  const int K0 = choose_k0(w, c.max_sym, N);
-  const int K1 = 32 / w;
-  const int low_bit = 64 - K0 * w;  // >= 8
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
+  const KeyPlan kp = plan_keys(span, N);
+  const int K0 = kp.K0;
+  const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
+  const int low_bit = 64 - K0 * kp.w - kp.fbits;  // >= 8; the end field counts as part of the sorted key
   const u64 sym_mask = ~0ull << low_bit;
   const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
   DBuf<u64> kb0(c, stride), kb1(c, stride);
@@ -464,7 +488,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     const int begin_bit = low_bit & ~7;
     int passes = (64 - begin_bit) / 8;
     Phase ph(c, "leaf_radix_sort", (double)N * (passes * 28 - 15));
-    TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0};
+    TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.fbits};
     cur = leaf_sort_text_keys(c, keys, vals, N, stride, begin_bit, tk);
   }
   const SplitKeys sorted_keys{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride};
@@ -514,7 +538,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     DBuf<u32> cp0(c, M), cp1(c, M);
     if (text_round) {
       hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos,
-                         wl_grp, M, (u32)h, w, K1, ck0.get(), cp0.get());
+                         wl_grp, M, (u32)h, c.sym_bits, K1, ck0.get(), cp0.get());
     } else {
       if (!isa.get()) {
         h_exact = h;
@@ -559,7 +583,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   em.sa = sa;
   em.N = N;
   em.sym_mask = sym_mask;
-  em.prev_mask = (1u << w) - 1;
+  em.prev_mask = 0xFFu;
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
   {
     Phase ph(c, "leaf_emit", (double)N * 12 + (double)(b - a) * 2);
