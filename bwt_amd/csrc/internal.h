@@ -163,22 +163,23 @@ void scan_inclusive_max_u32(Ctx &c, const u32 *in, u32 *out, size_t n);
 // holds the result.  n < 2^32.  `use` picks a kernel instantiation named after
 // the caller (0 leaf sort, 1 refinement rounds and tests, 2 gap histogram).
 // Keys that are a function of the text (round 0 of the leaf suffix sort), value(i) = a+i:
-//   key(i) = | codes of the K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest | end field, fbits |
-//            | zero padding | T[a+i-1] as it is, 8 bits |
+//   key(i) = | codes of the K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest | zero padding |
+//            | T[a+i-1] as it is, 8 bits |
 // The terminator and positions past the end have code 0.  Two codings:
-//   one_based = 1: code(c) = c - min_sym + 1, fbits = 0.  Exact: 0 is below every symbol.
+//   one_based = 1: code(c) = c - min_sym + 1.  Exact: 0 is below every symbol.
 //   one_based = 0: code(c) = c - min_sym, which saves a bit per symbol when the number of distinct symbols is
-//     a power of two (DNA: 2 bits).  The terminator then looks like the smallest symbol, so the keys of the
-//     at most K0 suffixes whose K0 symbols reach the terminator are told apart by the end field:
-//     K0 - (number of the K0 positions at or past the terminator), K0 for every other suffix.  Among equal
-//     codes a suffix that ends earlier is the smaller one, which is the order of the field; every other
-//     suffix has the largest value.  Keys (codes and end field) thus order the suffixes exactly to depth K0.
+//     a power of two (DNA: 2 bits).  The terminator then looks like the smallest symbol.  Where keys differ
+//     their order is still the order of the suffixes (a terminator coded as the smallest symbol can only turn
+//     a strict inequality into an equality).  Among equal keys, the (at most K0) suffixes whose K0 symbols
+//     reach the terminator precede all others, a shorter one before a longer one.  That is the order of
+//     DECREASING position, which the sort produces without looking: its first pass leaves equal digits in
+//     reverse input order and the later passes are stable.
 struct TextKeys {
   const u8 *T;
   u64 n, a;
   int w, K0;
   u32 min_sym;
-  int one_based, fbits;
+  int one_based;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).

@@ -48,7 +48,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nblk) {
 // ----------------------------------------------------------------------------
 // keys rolled out of the text (first pass of the leaf suffix sort)
 //   key(i) = | codes of the K0 symbols T[a+i .. a+i+K0), w bits each, first symbol highest,
-//              left-aligned | end field | zero padding | T[a+i-1] in the low 8 bits |   (TextKeys in internal.h)
+//              left-aligned | zero padding | T[a+i-1] in the low 8 bits |   (TextKeys in internal.h)
 //   value(i) = a + i
 // Positions >= n read as 0; T[-1] is T[n-1].
 // ----------------------------------------------------------------------------
@@ -81,11 +81,10 @@ __device__ __forceinline__ void tk_stage(u32 *S32, const TextKeys &tk, u64 tile0
 }
 
 // keys k0 .. k0+ITEMS-1 of the tile (k0 a multiple of 4), from the staged text
-// tile0 + k0 = window index of the first key
 template <int ITEMS>
-__device__ __forceinline__ void tk_roll(const u32 *S32, u64 tile0, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
-  const int w = tk.w, K0 = tk.K0, fb = tk.fbits;
-  const int used = K0 * w;  // used + fb <= 56
+__device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
+  const int w = tk.w, K0 = tk.K0;
+  const int used = K0 * w;  // <= 56
   const u64 maskall = (1ull << used) - 1;
   const int lsh = 64 - used;
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
@@ -99,18 +98,9 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u64 tile0, u32 k0, const
     sf = (sf << w) | (ch ? ch - ms : 0u);
     wd >>= 8;
   }
-  // the first position whose K0 symbols reach the terminator (position n-1)
-  const long long pos0 = (long long)(tk.a + tile0 + k0);
-  const long long reach = (long long)tk.n - K0;
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    u64 key = (sf << lsh) | raw[j - 1];  // the preceding symbol as it is
-    if (fb) {
-      long long e = pos0 + j - reach + 1;  // of the K0 positions, those at or past the terminator
-      e = e < 0 ? 0 : (e > K0 ? K0 : e);
-      key |= (u64)(K0 - e) << (lsh - fb);
-    }
-    key_out[j] = key;
+    key_out[j] = (sf << lsh) | raw[j - 1];  // the preceding symbol as it is
     const int k = K0 + j;
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
@@ -136,7 +126,7 @@ __global__ void __launch_bounds__(RH_THREADS)
     tk_stage(stage, tk, tile0, tid, RH_THREADS);
     __syncthreads();
     u64 key[RH_ITEMS];
-    tk_roll<RH_ITEMS>(stage, tile0, tid * RH_ITEMS, tk, key);
+    tk_roll<RH_ITEMS>(stage, tid * RH_ITEMS, tk, key);
 #pragma unroll
     for (int r = 0; r < RH_ITEMS; r++) {
       u32 d = (u32)(key[r] >> shift) & mask;
@@ -146,7 +136,7 @@ __global__ void __launch_bounds__(RH_THREADS)
     u32 tot = 0;
 #pragma unroll
     for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-    counts[(size_t)tid * nblk + tile] = tot;
+    counts[(size_t)tid * nblk + (nblk - 1 - tile)] = tot;  // tiles in reverse: this pass is reverse-stable
     return;
   }
   K key[RH_ITEMS];
@@ -202,7 +192,9 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Ranking, ordering in LDS and writing of one tile.  FULL: the tile has all RS_TILE keys.
-template <class K, bool HAS_VALS, bool FULL, bool SPLIT>
+// REVERSE: equal digits leave in the reverse of their input order, over the whole array (the caller's
+// histogram is then laid out with the tiles in reverse, see k_rs_hist).
+template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE>
 __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
                                                 u32 *gbase, u32 *scan_s, K *__restrict__ kout,
                                                 u32 *__restrict__ vout, u32 tile_n, int shift, u32 mask,
@@ -258,13 +250,16 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
     if (tid < 256) {
       u32 ds = incl - tot;
-      dstart[tid] = ds;
-      gbase[tid] = offs[(size_t)tid * nblk + tile] - ds;
+      dstart[tid] = REVERSE ? ds + tot - 1 : ds;  // reverse: the digit's last slot in the tile
+      gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
     }
   }
   lds_barrier();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) rk[r] += dstart[dig[r]] + myc[dig[r]];  // position inside the tile
+  for (int r = 0; r < RS_ITEMS; r++) {  // position inside the tile
+    if (REVERSE) rk[r] = dstart[dig[r]] - (myc[dig[r]] + rk[r]);
+    else rk[r] += dstart[dig[r]] + myc[dig[r]];
+  }
   lds_barrier();  // counters are dead from here: the buffer becomes the staging area
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
@@ -331,7 +326,7 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     tk_stage(stage, tk, tile0, tid, RS_THREADS);
     __syncthreads();
     u64 mine[RS_ITEMS];
-    tk_roll<RS_ITEMS>(stage, tile0, tid * RS_ITEMS, tk, mine);
+    tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) ex[tid * (RS_ITEMS + 1) + j] = mine[j];
     __syncthreads();
@@ -386,10 +381,10 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     }
   }
   if (full)
-    rs_scatter_tile<K, HAS_VALS, true, SPLIT>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
+    rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride);
   else
-    rs_scatter_tile<K, HAS_VALS, false, SPLIT>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
+    rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride);
 }
 

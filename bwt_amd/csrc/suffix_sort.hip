@@ -64,15 +64,21 @@ struct SplitKeys {
   }
 };
 
+// zero_low_unique (refinement rounds): a key whose low word is 0 is never tied.  That word is the
+// secondary key "nothing is left of the suffix at this depth"; several such suffixes in one group are the
+// ones that ran into the terminator inside their round-0 key (TextKeys, zero-based coding), they already
+// stand in their final order and the stable sort has kept it.
 template <class Keys>
 struct GroupIn {
   Keys key;
   size_t n;
   u64 mask;  // the key bits that count
+  bool zero_low_unique;
+  __device__ __forceinline__ bool same(u64 x, u64 y) const { return x == y && !(zero_low_unique && (u32)x == 0); }
   __device__ __forceinline__ TieHead operator()(size_t i) const {
     u64 k = key[i] & mask;
-    bool head = (i == 0) || (key[i - 1] & mask) != k;
-    bool next_head = (i + 1 == n) || (key[i + 1] & mask) != k;
+    bool head = (i == 0) || !same(key[i - 1] & mask, k);
+    bool next_head = (i + 1 == n) || !same(key[i + 1] & mask, k);
     return TieHead{(u32)!(head && next_head), head ? (u32)(i + 1) : 0u};
   }
 };
@@ -230,7 +236,7 @@ __global__ void k_direct_finish(const u8 *__restrict__ T, u64 n, const u32 *__re
     for (u32 d = 0; d < DF_DEPTH; d++) {
       const bool ey = y + d >= n, ex = x + d >= n;
       if (ey || ex) {
-        less = ey && !ex;
+        less = ey && (!ex || y > x);  // nothing left of either: the shorter suffix is the smaller
         decided = true;
         break;
       }
@@ -429,8 +435,9 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
 // pass over the whole window; fewer symbols leave more suffixes tied for the refinement, which only touches
 // the tied ones.  Take the coding and the fewest passes for which a random text of this alphabet would leave
 // under 5 % tied (below that, ordering the ties by direct comparison is cheaper than another pass).
+// Codings: see TextKeys.
 struct KeyPlan {
-  int w, K0, one_based, fbits, passes;
+  int w, K0, one_based, passes;
 };
 
 static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
@@ -442,12 +449,7 @@ static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
     const int w = bits_for((u64)(span + one_based));
     if (!one_based && w == bits_for((u64)(span + 1))) continue;  // no bit saved: keep the exact coding
     for (int passes = 1; passes <= 7; passes++) {
-      // most symbols with K0*w + fbits <= 8*passes (and <= 56: the low byte is the preceding symbol)
-      int K0 = 0;
-      for (int k = 1; k * w <= 8 * passes; k++) {
-        int fb = one_based ? 0 : bits_for((u64)k);
-        if (k * w + fb <= 8 * passes) K0 = k;
-      }
+      const int K0 = 8 * passes / w;  // <= 56 / w: the low byte is the preceding symbol
       if (K0 < 1) continue;
       double distinct = 1;
       for (int j = 0; j < K0 && distinct < 1e30; j++) distinct *= sigma;
@@ -456,7 +458,7 @@ static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
       const bool better = best.K0 == 0 || (good && (best_tied > 0.05 || passes < best.passes)) ||
                           (!good && best_tied > 0.05 && tied < best_tied);
       if (better) {
-        best = KeyPlan{w, K0, one_based, one_based ? 0 : bits_for((u64)K0), passes};
+        best = KeyPlan{w, K0, one_based, passes};
         best_tied = tied;
       }
       if (good) break;  // more passes of this coding cannot be better
@@ -474,7 +476,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
   const KeyPlan kp = plan_keys(span, N);
   const int K0 = kp.K0;
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
-  const int low_bit = 64 - K0 * kp.w - kp.fbits;  // >= 8; the end field counts as part of the sorted key
+  const int low_bit = 64 - K0 * kp.w;  // >= 8
   const u64 sym_mask = ~0ull << low_bit;
   const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
   DBuf<u64> kb0(c, stride), kb1(c, stride);
@@ -488,7 +490,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     const int begin_bit = low_bit & ~7;
     int passes = (64 - begin_bit) / 8;
     Phase ph(c, "leaf_radix_sort", (double)N * (passes * 28 - 15));
-    TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.fbits};
+    TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based};
     cur = leaf_sort_text_keys(c, keys, vals, N, stride, begin_bit, tk);
   }
   const SplitKeys sorted_keys{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride};
@@ -559,7 +561,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     c.sort_tag = "";
     DBuf<u32> ns(c, M), np(c, M), ng(c, M);
     scan_generic<TieHead, TieHeadOp>(
-        c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull},
+        c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull, true},
         RefineOut{wl_slot, cp[cc], sa, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
     M = read_u32(c, d_total);
     nl_slot = std::move(ns);

@@ -124,3 +124,27 @@ def test_leaf_window_above_2_31(ctx):
     assert counts[0] == 1 and counts[1:5].sum() == n - 1 and abs(int(counts[1]) - n // 4) < 200000
     T = ctx.get_text()
     assert (L2[r] == T[p - 1]).all()  # L[rank] = T[pos-1] for every sample (index -1 is the last symbol, as it should be)
+
+
+@pytest.mark.parametrize("sigma", [2, 4, 8, 3])
+@pytest.mark.parametrize("tail", [0, 1, 5, 19, 20, 21, 40, 300])
+def test_text_ends_in_a_run_of_the_smallest_symbol(ctx, sigma, tail):
+    """Alphabets of 2^k symbols get zero-based symbol codes in the sort keys, where the terminator looks like the
+    smallest symbol: suffixes that end inside the key width, alone or in a run of the smallest symbol, must still
+    come out in their place (several leaves, so that windows with and without the text's end are sorted)."""
+    rng = np.random.default_rng(1000 * sigma + tail)
+    body = rng.integers(1, sigma + 1, size=30000, dtype=np.uint8)
+    body[rng.integers(0, 30000, size=40)] = 1  # more runs of the smallest symbol inside the text
+    T = np.concatenate([body, np.full(tail, 1, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
+    _same_as_oracle(ctx, T, sigma, len(T), 200)
+    _same_as_oracle(ctx, T, sigma, 9000, 200, 50)
+
+
+def test_binary_text_of_long_runs(ctx):
+    """Two symbols, long runs of each, ending in a long run of the smaller one."""
+    rng = np.random.default_rng(77)
+    runs = rng.integers(1, 200, size=400)
+    T = np.concatenate([np.full(r, 1 + (i & 1), dtype=np.uint8) for i, r in enumerate(runs)] +
+                       [np.full(150, 1, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
+    _same_as_oracle(ctx, T, 2, len(T), 100)
+    _same_as_oracle(ctx, T, 2, 7000, 100)
