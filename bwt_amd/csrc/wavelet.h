@@ -55,7 +55,7 @@ __device__ __forceinline__ u32 wm_rank_digit(const u64 *__restrict__ lvl, u32 po
   uint4 hdr = p[0];
   uint4 ch[WM_CHUNKS];
 #pragma unroll
-  for (u32 k = 0; k < WM_CHUNKS; k++) ch[k] = (k <= wi) ? p[1 + k] : make_uint4(0, 0, 0, 0);
+  for (u32 k = 0; k < WM_CHUNKS; k++) ch[k] = p[1 + k];  // the whole block: one sector, no per-lane branches
   u32 cnt = d == 0 ? hdr.x : (d == 1 ? hdr.y : (d == 2 ? hdr.z : hdr.w));
   const u64 inv0 = (d & 1) ? 0ull : ~0ull, inv1 = (d & 2) ? 0ull : ~0ull;
   const u64 part = (1ull << bi) - 1;
