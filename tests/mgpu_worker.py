@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--lpr", type=int, default=2)
     ap.add_argument("--ns", type=int, default=500)
     ap.add_argument("--seg", type=int, default=0)
+    ap.add_argument("--direct", type=int, default=0, help="dist algo: 1 = hand the ops' tensors to the transport as they are (what an nccl run does)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import torch.distributed as dist
@@ -214,8 +215,9 @@ def main():
             opt = Oracle.opt(args.n, alpha_min=1, alpha_max=args.sigma, ssa_n_samples=args.ns, build_gap_segment_sz=args.seg)
             ops = NumpyDistOps(T, opt, args.ns, args.seg, th)
         groups = dist_merge.make_groups(dist, world)
-        blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, True)
-        L = dist_merge.gather_L(blk, rank, world, dist, dev, True)
+        staging = not args.direct
+        blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, staging)
+        L = dist_merge.gather_L(blk, rank, world, dist, dev, staging)
         if rank == 0:
             np.savez(args.out, L=L, rank=blk.samp_rank.cpu().numpy(), pos=blk.samp_pos.cpu().numpy(), s_rank=blk.s_rank,
                      e_rank=blk.e_rank, sizes=np.array(blk.sizes))

@@ -77,14 +77,16 @@ def test_dist_bounds_partition_the_left_ranks():
         assert (m * scale) >> 32 < parts
 
 
-@pytest.mark.parametrize("world,lpr", [(2, 1), (4, 1), (4, 2), (8, 1)])
-def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr):
+@pytest.mark.parametrize("world,lpr,direct", [(2, 1, 0), (4, 1, 0), (4, 2, 1), (8, 1, 1), (2, 1, 1)])
+def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr, direct):
     """Every merge spread over all ranks of its subtree (bwt_amd/dist_merge.py), the per-part steps done in numpy:
-    the exchange pattern and the bookkeeping are what is tested; the result must be the block of the same tree."""
+    the exchange pattern and the bookkeeping are what is tested; the result must be the block of the same tree.
+    direct = 1 hands the tensors to the transport without host staging: receives land in slices of the destination
+    buffer, broadcasts and sums work in place -- the code path of an nccl run."""
     n, ns, seg = 24000, 300, 64
     out = str(tmp_path / "res.npz")
     _launch(world, ["--ops", "oracle", "--algo", "dist", "--text_len", str(n), "--lpr", str(lpr), "--ns", str(ns),
-                    "--seg", str(seg)], out)
+                    "--seg", str(seg), "--direct", str(direct)], out)
     res = np.load(out)
     T = gen_text(n, 42, 4)
     th = multi_gpu.leaf_threshold(n, world * lpr)
