@@ -5,21 +5,27 @@ import os
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec sheet); a plain copy kernel reaches about 6300 GB/s
 SECTOR = 64            # bytes the memory side moves for one random rank-block read
 
-DOMINANT = "leaf:k_rs_scatter_u64_pairs"
+# the leaf sort's scatter pass, in whichever layout the run used: (timer, kernel, algorithmic bytes per suffix)
+DOMINANT = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<u64,keys> (packed 8-byte elements)", 16),
+            ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<u64,pairs,split>", 24)]
 
 # what a timer's `work` counts, for timers that do not count bytes
 TRANSACTION_TIMERS = {"gap_chains": "64-byte random reads (one rank block per wavelet level and LF step, text every 16th step)"}
 
 
 def roofline(timers, repo_root=None, workload=None):
-    """HBM roofline of the dominant kernel: the leaf sort's scatter pass, 24 algorithmic bytes per suffix
-    (reads 8-byte key + 4-byte position, writes the same).  `work` of that timer is bytes summed over launches."""
-    if DOMINANT not in timers or timers[DOMINANT][2] <= 0:
+    """HBM roofline of the dominant kernel: the leaf sort's scatter pass, which reads and writes every element
+    once (16 algorithmic bytes per suffix with packed elements, 24 with key + position pairs).  `work` of its
+    timer is bytes summed over launches."""
+    found = [d for d in DOMINANT if d[0] in timers and timers[d[0]][2] > 0]
+    if not found:
         return None
-    ms, work, calls = timers[DOMINANT]
+    name, kernel, per_suffix = max(found, key=lambda d: timers[d[0]][0])
+    ms, work, calls = timers[name]
     achieved = work / (ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_rs_scatter<u64,pairs,split>",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+            "algorithmic_bytes_per_suffix": per_suffix,
             "bytes_per_launch": work / calls, "avg_launch_ms": round(ms / calls, 4), "launches": calls}
     # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
     # runs, corrected as the gfx950 notes prescribe); only valid for the workload they were taken on
@@ -27,7 +33,7 @@ def roofline(timers, repo_root=None, workload=None):
         tfile = os.path.join(repo_root, "profiles", "r1_traffic_rs_scatter.json")
         if os.path.exists(tfile):
             t = json.load(open(tfile))
-            if t.get("workload") == workload:
+            if t.get("workload") == workload and t.get("timer", "leaf:k_rs_scatter_u64_pairs") == name:
                 roof["traffic"] = t["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r1_traffic_rs_scatter.json"
     return roof

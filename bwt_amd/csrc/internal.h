@@ -180,6 +180,9 @@ struct TextKeys {
   int w, K0;
   u32 min_sym;
   int one_based;
+  // 0: (key, value) pairs as above.  Otherwise PACKED 8-byte elements (K0 * w <= 32, window below 2^pbits):
+  //   | codes, 32 bits | T[a+i-1], 32 - pbits bits | i, pbits bits |
+  int pbits;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
@@ -187,6 +190,8 @@ int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 // `stride` 32-bit words further.  Returns the buffer that holds the result.
 int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride, int begin_bit,
                         const TextKeys &text);
+// The same for packed elements (text.pbits != 0): sorts them on bits [begin_bit, 64), begin_bit >= 32.
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------

@@ -300,7 +300,9 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
   // the tile's keys and values in digit order.
   constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
   constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
-  constexpr size_t BUF_BYTES = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
+  constexpr size_t TEXT_BYTES = TEXT ? (size_t)RS_THREADS * (RS_ITEMS + 1) * 8 + TK_STAGE_WORDS * 4 : 0;  // key exchange + staged text
+  constexpr size_t BUF0 = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
+  constexpr size_t BUF_BYTES = BUF0 > TEXT_BYTES ? BUF0 : TEXT_BYTES;
   __shared__ __align__(16) unsigned char buf[BUF_BYTES];
   __shared__ u32 gbase[256];
   __shared__ u32 scan_s[17];
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     // The same buffer first holds the staged text (behind the key exchange area) and the keys that
     // thread t rolled for tile indices 8t .. 8t+7, 9 words apart per thread against bank conflicts;
     // every thread then picks up the keys of its ranking slots.
-    static_assert(sizeof(K) == 8 && HAS_VALS, "text keys are 64-bit and carry their position");
+    static_assert(sizeof(K) == 8 && !(SPLIT && !HAS_VALS), "text keys: 64-bit with a position, or packed elements");
     constexpr u32 EX_WORDS = RS_THREADS * (RS_ITEMS + 1);
     static_assert(EX_WORDS * 8 + TK_STAGE_WORDS * 4 <= BUF_BYTES, "exchange area and staged text share the buffer");
     K *ex = reinterpret_cast<K *>(buf);
@@ -335,8 +337,13 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     for (int r = 0; r < RS_ITEMS; r++) {
       u32 idx = wbase + r * 64 + lane;
       bool valid = idx < tile_n;
-      key[r] = valid ? ex[(idx / RS_ITEMS) * (RS_ITEMS + 1) + (idx % RS_ITEMS)] : (K)0;
-      val[r] = pos0 + idx;
+      u64 k = valid ? ex[(idx / RS_ITEMS) * (RS_ITEMS + 1) + (idx % RS_ITEMS)] : 0ull;
+      if constexpr (HAS_VALS) {
+        key[r] = (K)k;
+        val[r] = pos0 + idx;
+      } else {  // packed element: codes | preceding symbol | window index
+        key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
+      }
     }
     __syncthreads();  // the exchange area becomes the counters
   } else if constexpr (SPLIT) {
@@ -484,6 +491,56 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
         hipLaunchKernelGGL((k_rs_scatter<u64, true, 0, false, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                            keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk,
                            none, stride);
+        HIP_CHECK(hipGetLastError());
+      }
+    }
+    cur ^= 1;
+  }
+  return cur;
+}
+
+// Round 0 with packed elements (TextKeys::pbits != 0): the first pass builds the elements from the text
+// (reverse-stable, see TextKeys), the others are plain stable passes over 8-byte keys without values.
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text) {
+  if (n == 0) return 0;
+  if (begin_bit % 8 != 0 || begin_bit < 32 || begin_bit >= 64 || text.pbits <= 0 || text.pbits > 31 ||
+      (n - 1) >> text.pbits)
+    fail(BWT_HIP_EINTERNAL, "leaf sort: bad packed layout (begin_bit %d, pbits %d, n %zu)", begin_bit, text.pbits, n);
+  u32 nblk = ceil_div(n, RS_TILE);
+  DBuf<u32> counts(c, (size_t)256 * nblk);
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  int cur = 0;
+  for (int shift = begin_bit; shift < 64; shift += 8) {
+    const u32 mask = 255u;
+    if (shift == begin_bit) {
+      {
+        KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
+        hipLaunchKernelGGL((k_rs_hist<u64, 0, true>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr,
+                           n, shift, mask, counts.get(), nblk, text);
+        HIP_CHECK(hipGetLastError());
+      }
+      scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+      {
+        KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
+        hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                           (const u64 *)nullptr, (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask,
+                           counts.get(), nblk, text, 0u);
+        HIP_CHECK(hipGetLastError());
+      }
+    } else {
+      {
+        KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
+        hipLaunchKernelGGL((k_rs_hist<u64, 0, false>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, elems[cur], n, shift,
+                           mask, counts.get(), nblk, none);
+        HIP_CHECK(hipGetLastError());
+      }
+      scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+      {
+        KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
+        hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                           elems[cur], (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask,
+                           counts.get(), nblk, none, 0u);
         HIP_CHECK(hipGetLastError());
       }
     }

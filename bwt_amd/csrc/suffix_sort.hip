@@ -2,11 +2,13 @@
 // suffixes (what the reference's idx_less comparison sort produces,
 // include/suffix_array.h:14-49), by radix sort + prefix doubling.
 //
-//   round 0   key = first K0 symbols packed into 64 bits (plus the preceding
-//             symbol in the low bits, which is not sorted on and later yields the
-//             BWT symbol without a read of the text); LSD radix sort of
-//             (key, position) over the window [a, e), e = b + slack; the first
-//             pass computes the keys from the text on the fly
+//   round 0   key = codes of the first K0 symbols (plus the preceding symbol,
+//             which is not sorted on and later yields the BWT symbol without a
+//             read of the text); LSD radix sort over the window [a, e),
+//             e = b + slack; the first pass computes the keys from the text on
+//             the fly.  Two layouts (TextKeys in internal.h): (key, position)
+//             pairs of 12 bytes, or -- small alphabets, windows below 2^29 --
+//             one 8-byte element holding codes, preceding symbol and position
 //   tie list  suffixes whose key is shared form groups; only those stay active
 //   direct    if ties are sparse, small groups are ordered by comparing the text
 //             itself (on random text this ends the sort); given up as a whole
@@ -46,23 +48,75 @@ struct TieHeadOp {
   }
 };
 
-// 64-bit keys held as one array, or split into low and high words (the layout of the round-0 sort)
+// 64-bit keys held as one array (refinement rounds)
 struct PlainKeys {
   const u64 *p;
   __device__ __forceinline__ u64 operator[](size_t i) const { return p[i]; }
 };
-struct SplitKeys {
-  const u32 *lo, *hi;  // both 16-byte aligned
-  __device__ __forceinline__ u64 operator[](size_t i) const { return ((u64)hi[i] << 32) | lo[i]; }
-  // keys i0 .. i0+3, i0 a multiple of four
-  __device__ __forceinline__ void load4(size_t i0, u64 (&k)[4]) const {
+
+// The sorted window after round 0, in either layout.  key(i): symbol codes in the top bits, the preceding
+// symbol in the low byte.  pos(i): text position.  low(i): the part of an element that moves when a tie is
+// resolved (packed layout only).  i0 of the *4 forms is a multiple of four.
+struct PairsView {
+  const u32 *lo, *hi;  // key words, both 16-byte aligned
+  const u32 *sa;
+  __device__ __forceinline__ u64 key(size_t i) const { return ((u64)hi[i] << 32) | lo[i]; }
+  __device__ __forceinline__ u32 pos(size_t i) const { return sa[i]; }
+  __device__ __forceinline__ u32 low(size_t) const { return 0; }
+  __device__ __forceinline__ void key4(size_t i0, u64 (&k)[4]) const {
     const uint4 l = *reinterpret_cast<const uint4 *>(lo + i0), h = *reinterpret_cast<const uint4 *>(hi + i0);
     k[0] = ((u64)h.x << 32) | l.x;
     k[1] = ((u64)h.y << 32) | l.y;
     k[2] = ((u64)h.z << 32) | l.z;
     k[3] = ((u64)h.w << 32) | l.w;
   }
+  __device__ __forceinline__ void pos4(size_t i0, u32 (&p)[4]) const {
+    const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+    p[3] = v.w;
+  }
 };
+struct PackedView {
+  const u64 *e;    // | codes, 32 bits | preceding symbol | position - a, pbits |
+  const u32 *sa;   // null, or the positions once refinement rounds have taken them over
+  u32 a, posmask;
+  int pbits;
+  __device__ __forceinline__ u64 cvt(u64 x) const { return (x & 0xFFFFFFFF00000000ull) | ((u32)x >> pbits); }
+  __device__ __forceinline__ u64 key(size_t i) const { return cvt(e[i]); }
+  __device__ __forceinline__ u32 pos(size_t i) const { return sa ? sa[i] : a + ((u32)e[i] & posmask); }
+  __device__ __forceinline__ u32 low(size_t i) const { return (u32)e[i]; }
+  __device__ __forceinline__ void raw4(size_t i0, u64 (&x)[4]) const {
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(e + i0), v1 = *reinterpret_cast<const uint4 *>(e + i0 + 2);
+    x[0] = ((u64)v0.y << 32) | v0.x;
+    x[1] = ((u64)v0.w << 32) | v0.z;
+    x[2] = ((u64)v1.y << 32) | v1.x;
+    x[3] = ((u64)v1.w << 32) | v1.z;
+  }
+  __device__ __forceinline__ void key4(size_t i0, u64 (&k)[4]) const {
+    raw4(i0, k);
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j] = cvt(k[j]);
+  }
+  __device__ __forceinline__ void pos4(size_t i0, u32 (&p)[4]) const {
+    if (sa) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
+      p[0] = v.x;
+      p[1] = v.y;
+      p[2] = v.z;
+      p[3] = v.w;
+    } else {
+      u64 x[4];
+      raw4(i0, x);
+#pragma unroll
+      for (int j = 0; j < 4; j++) p[j] = a + ((u32)x[j] & posmask);
+    }
+  }
+};
+
+__device__ __host__ inline void set_positions(PairsView &, const u32 *) {}
+__device__ __host__ inline void set_positions(PackedView &v, const u32 *sa) { v.sa = sa; }
 
 // zero_low_unique (refinement rounds): a key whose low word is 0 is never tied.  That word is the
 // secondary key "nothing is left of the suffix at this depth"; several such suffixes in one group are the
@@ -83,25 +137,25 @@ struct GroupIn {
   }
 };
 
-// the same for four consecutive elements of split keys: two 16-byte loads and the two neighbours
-template <>
-struct GroupIn<SplitKeys> {
-  SplitKeys key;
+// ties of the sorted window: four consecutive elements at a time
+template <class View>
+struct ViewTies {
+  View v;
   size_t n;
   u64 mask;
   __device__ __forceinline__ TieHead operator()(size_t i) const {
-    u64 k = key[i] & mask;
-    bool head = (i == 0) || (key[i - 1] & mask) != k;
-    bool next_head = (i + 1 == n) || (key[i + 1] & mask) != k;
+    u64 k = v.key(i) & mask;
+    bool head = (i == 0) || (v.key(i - 1) & mask) != k;
+    bool next_head = (i + 1 == n) || (v.key(i + 1) & mask) != k;
     return TieHead{(u32)!(head && next_head), head ? (u32)(i + 1) : 0u};
   }
   __device__ __forceinline__ void vec4(size_t i0, TieHead *out) const {
     u64 k[6], c[4];
-    key.load4(i0, c);
+    v.key4(i0, c);
 #pragma unroll
     for (int j = 0; j < 4; j++) k[j + 1] = c[j] & mask;
-    k[0] = i0 ? (key[i0 - 1] & mask) : ~k[1];
-    k[5] = (i0 + 4 < n) ? (key[i0 + 4] & mask) : ~k[4];
+    k[0] = i0 ? (v.key(i0 - 1) & mask) : ~k[1];
+    k[5] = (i0 + 4 < n) ? (v.key(i0 + 4) & mask) : ~k[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       bool head = k[j] != k[j + 1], next_head = k[j + 1] != k[j + 2];
@@ -110,18 +164,20 @@ struct GroupIn<SplitKeys> {
   }
 };
 
-// after round 0: emit the active list (slot = rank index, pos, group = head rank)
+// after round 0: emit the active list (slot = rank index, pos, group = head rank; low: see View)
+template <class View>
 struct FirstListOut {
-  const u32 *sa;
-  u32 *slot, *pos, *grp;
+  View v;
+  u32 *slot, *pos, *grp, *low;  // low may be null
   u32 *total;
   size_t n;
   __device__ __forceinline__ void operator()(size_t i, TieHead ex, TieHead in) const {
     if (in.cnt != ex.cnt) {
       u32 k = ex.cnt;
       slot[k] = (u32)i;
-      pos[k] = sa[i];
+      pos[k] = v.pos(i);
       grp[k] = in.hmax - 1;
+      if (low) low[k] = v.low(i);
     }
     if (i + 1 == n) *total = in.cnt;
   }
@@ -214,7 +270,7 @@ constexpr u32 DF_GROUP = 32;
 constexpr u32 DF_DEPTH = 512;
 
 __global__ void k_direct_finish(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ pos,
-                                const u32 *__restrict__ grp, u32 M, u64 h, u32 *__restrict__ out_pos,
+                                const u32 *__restrict__ grp, u32 M, u64 h, u32 *__restrict__ out_src,
                                 u32 *__restrict__ fail) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
@@ -253,13 +309,26 @@ __global__ void k_direct_finish(const u8 *__restrict__ T, u64 n, const u32 *__re
     }
     smaller += less;
   }
-  out_pos[lo + smaller] = pos[k];
+  out_src[lo + smaller] = k;  // list entry lo + smaller receives this suffix
 }
 
-__global__ void k_direct_commit(const u32 *__restrict__ slot, const u32 *__restrict__ new_pos, u32 M,
-                                u32 *__restrict__ sa) {
+// pairs layout: the position moves
+__global__ void k_direct_commit(const u32 *__restrict__ slot, const u32 *__restrict__ src, const u32 *__restrict__ pos,
+                                u32 M, u32 *__restrict__ sa) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < M) sa[slot[k]] = new_pos[k];
+  if (k < M) sa[slot[k]] = pos[src[k]];
+}
+
+// packed layout: the element's low word (preceding symbol and position) moves; the codes are the group's
+__global__ void k_direct_commit_packed(const u32 *__restrict__ slot, const u32 *__restrict__ src,
+                                       const u32 *__restrict__ low, u32 M, u64 *__restrict__ e) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < M) reinterpret_cast<u32 *>(e + slot[k])[0] = low[src[k]];
+}
+
+__global__ void k_unpack_pos(const u64 *__restrict__ e, u32 N, u32 a, u32 posmask, u32 *__restrict__ sa) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) sa[i] = a + ((u32)e[i] & posmask);
 }
 
 __global__ void k_isa_init(const u32 *__restrict__ sa, u32 a, u32 N, u32 *__restrict__ isa) {
@@ -277,18 +346,22 @@ __global__ void k_isa_fix(const u32 *__restrict__ pos, const u32 *__restrict__ g
 // final pass: the leaf's BWT, special ranks and samples straight from the sorted
 // window (reference: include/bwt.h:589-609 sa_to_bwt, :294-361 sample_sa)
 // ----------------------------------------------------------------------------
-struct LeafEmit {
+struct EmitParams {
   const u8 *T;
   u64 n, a, m;
   i64 ns;            // samples to take (already min(m, ssa_n_samples))
   u8 *L;             // may be null: suffix array only
   u32 *samp_rank, *samp_pos, *special;
+};
+
+template <class View>
+struct LeafEmit : EmitParams {
   u32 *sa_out;       // may be null
-  SplitKeys keys;    // sorted round-0 keys of the window
-  const u32 *sa;     // sorted window positions
+  View v;            // the sorted window
   u64 N;             // window length
   u64 sym_mask;      // symbol field of a key
-  u32 prev_mask;     // preceding-symbol field
+  bool prev_follows; // the preceding symbol travels with the position when ties are resolved (packed layout,
+                     // resolved by direct comparison): the key's low byte is right for tied suffixes too
 
   double samp_ratio; // (ns-1)/(m-1), only used to skip positions that are certainly not sampled
 
@@ -328,38 +401,43 @@ struct LeafEmit {
 
   // window rank i holds leaf rank r
   __device__ __forceinline__ void emit(u64 r, u64 i) const {
-    u32 pos = sa[i];
+    u32 pos = v.pos(i);
     if (sa_out) sa_out[r] = pos;
     if (!L) return;
-    u64 k = keys[i];
+    u64 k = v.key(i);
     u64 top = k & sym_mask;
-    bool tied = (i > 0 && (keys[i - 1] & sym_mask) == top) || (i + 1 < N && (keys[i + 1] & sym_mask) == top);
+    bool tied = !prev_follows && ((i > 0 && (v.key(i - 1) & sym_mask) == top) || (i + 1 < N && (v.key(i + 1) & sym_mask) == top));
     // a suffix that round 0 placed still sits next to its key; a refined one moved, so read the text
-    L[r] = tied ? sym_before(pos) : (u8)((u32)k & prev_mask);
+    L[r] = tied ? sym_before(pos) : (u8)((u32)k & 0xFFu);
     note(r, pos);
   }
 
   // BWT symbols of window ranks i0 .. i0+3 (i0 a multiple of four, all below N), from 16-byte loads
   __device__ __forceinline__ void symbols4(u64 i0, const u32 (&pos)[4], u32 (&ch)[4]) const {
     u64 k[6], c[4];
-    keys.load4(i0, c);
+    v.key4(i0, c);
+    if (prev_follows) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) ch[j] = (u32)c[j] & 0xFFu;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) k[j + 1] = c[j];
-    k[0] = i0 ? keys[i0 - 1] : ~c[0];
-    k[5] = (i0 + 4 < N) ? keys[i0 + 4] : ~c[3];
+    k[0] = i0 ? v.key(i0 - 1) : ~c[0];
+    k[5] = (i0 + 4 < N) ? v.key(i0 + 4) : ~c[3];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       u64 top = k[j + 1] & sym_mask;
       bool tied = (k[j] & sym_mask) == top || (k[j + 2] & sym_mask) == top;
-      ch[j] = tied ? (u32)sym_before(pos[j]) : ((u32)k[j + 1] & prev_mask);
+      ch[j] = tied ? (u32)sym_before(pos[j]) : ((u32)k[j + 1] & 0xFFu);
     }
   }
 
   // four window ranks of a window that is the leaf itself (leaf rank == window rank): one 4-byte store of L
   __device__ __forceinline__ void emit4(u64 i0) const {
-    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
-    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
-    if (sa_out) *reinterpret_cast<uint4 *>(sa_out + i0) = p4;
+    u32 pos[4];
+    v.pos4(i0, pos);
+    if (sa_out) *reinterpret_cast<uint4 *>(sa_out + i0) = make_uint4(pos[0], pos[1], pos[2], pos[3]);
     if (!L) return;
     u32 ch[4];
     symbols4(i0, pos, ch);
@@ -370,8 +448,8 @@ struct LeafEmit {
 
   // four window ranks of a longer window: rank[j] is the leaf rank of i0+j where keep[j] says it belongs to the leaf
   __device__ __forceinline__ void emit4_filtered(u64 i0, const u32 (&rank)[4], const bool (&keep)[4]) const {
-    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i0);
-    const u32 pos[4] = {p4.x, p4.y, p4.z, p4.w};
+    u32 pos[4];
+    v.pos4(i0, pos);
     u32 ch[4] = {0, 0, 0, 0};
     if (L) symbols4(i0, pos, ch);
 #pragma unroll
@@ -386,7 +464,8 @@ struct LeafEmit {
   }
 };
 
-__global__ void k_emit_all(LeafEmit E) {
+template <class View>
+__global__ void k_emit_all(LeafEmit<View> E) {
   u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i0 + 4 <= E.N) {
     E.emit4(i0);
@@ -395,20 +474,21 @@ __global__ void k_emit_all(LeafEmit E) {
   }
 }
 
+template <class View>
 struct LeafFilterIn {
-  const u32 *sa;
+  View v;
   u32 b;
-  __device__ __forceinline__ u32 operator()(size_t i) const { return sa[i] < b; }
+  __device__ __forceinline__ u32 operator()(size_t i) const { return v.pos(i) < b; }
   __device__ __forceinline__ void vec4(size_t i0, u32 *out) const {
-    const uint4 p = *reinterpret_cast<const uint4 *>(sa + i0);
-    out[0] = p.x < b;
-    out[1] = p.y < b;
-    out[2] = p.z < b;
-    out[3] = p.w < b;
+    u32 p[4];
+    v.pos4(i0, p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = p[j] < b;
   }
 };
+template <class View>
 struct LeafFilterOut {
-  LeafEmit E;
+  LeafEmit<View> E;
   __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
     if (in != ex) E.emit(ex, i);
   }
@@ -431,16 +511,26 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
   return b;
 }
 
-// Layout of the round-0 key (TextKeys): coding, number of symbols K0.  Every 8 sorted key bits cost one radix
-// pass over the whole window; fewer symbols leave more suffixes tied for the refinement, which only touches
-// the tied ones.  Take the coding and the fewest passes for which a random text of this alphabet would leave
-// under 5 % tied (below that, ordering the ties by direct comparison is cheaper than another pass).
-// Codings: see TextKeys.
+// Layout of the round-0 key (TextKeys): coding, number of symbols K0, pairs or packed elements.  Every 8
+// sorted key bits cost one radix pass over the whole window; fewer symbols leave more suffixes tied for the
+// refinement, which only touches the tied ones.
+//   pairs:  the coding and the fewest passes for which a random text of this alphabet would leave under 5 %
+//           tied (below that, ordering the ties by direct comparison is cheaper than another pass).
+//   packed: 8-byte elements (codes in the high word, preceding symbol and window-relative position in the
+//           low word) move a third less per pass and need at most 4 passes; taken when the position and the
+//           preceding symbol fit the low word and the expected ties stay under 15 %.
 struct KeyPlan {
   int w, K0, one_based, passes;
+  int pbits;  // 0: pairs; otherwise the position bits of a packed element
 };
 
-static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
+static double expected_ties(double sigma, int K0, u64 N) {
+  double distinct = 1;
+  for (int j = 0; j < K0 && distinct < 1e30; j++) distinct *= sigma;
+  return (double)N / distinct;
+}
+
+static KeyPlan plan_keys(int span, int raw_bits, u64 N) {  // span = max_sym - min_sym; raw_bits holds any symbol
   const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
   KeyPlan best;
   memset(&best, 0, sizeof(best));
@@ -451,84 +541,96 @@ static KeyPlan plan_keys(int span, u64 N) {  // span = max_sym - min_sym
     for (int passes = 1; passes <= 7; passes++) {
       const int K0 = 8 * passes / w;  // <= 56 / w: the low byte is the preceding symbol
       if (K0 < 1) continue;
-      double distinct = 1;
-      for (int j = 0; j < K0 && distinct < 1e30; j++) distinct *= sigma;
-      const double tied = (double)N / distinct;
+      const double tied = expected_ties(sigma, K0, N);
       const bool good = tied <= 0.05;
       const bool better = best.K0 == 0 || (good && (best_tied > 0.05 || passes < best.passes)) ||
                           (!good && best_tied > 0.05 && tied < best_tied);
       if (better) {
-        best = KeyPlan{w, K0, one_based, passes};
+        best = KeyPlan{w, K0, one_based, passes, 0};
         best_tied = tied;
       }
       if (good) break;  // more passes of this coding cannot be better
     }
   }
+  // packed elements: codes <= 32 bits, low word = preceding symbol | position
+  const int pbits = bits_for(N - 1);
+  if (N >= 2 && pbits + raw_bits <= 32) {
+    for (int one_based = 1; one_based >= 0; one_based--) {
+      const int w = bits_for((u64)(span + one_based));
+      if (!one_based && w == bits_for((u64)(span + 1))) continue;
+      for (int passes = 1; passes <= 4; passes++) {
+        const int K0 = 8 * passes / w;
+        if (K0 < 1) continue;
+        if (expected_ties(sigma, K0, N) <= 0.15) {
+          if (best.pbits == 0 ? passes <= best.passes : passes < best.passes) best = KeyPlan{w, K0, one_based, passes, pbits};
+          break;
+        }
+      }
+    }
+  }
   return best;
 }
 
-// Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
-// been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
-static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_out) {
-  const u64 N = (u64)(e - a);
-  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
-  const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
-  const KeyPlan kp = plan_keys(span, N);
-  const int K0 = kp.K0;
+// Everything after the round-0 sort: tie list, refinement, emit.  sa_w: the writable positions (pairs
+// layout) or null; e_w: the writable elements (packed layout) or null.  scratch: 2N free 32-bit words for
+// the first active list; grp_buf: N more words (pairs: the unused value buffer).
+template <class View>
+static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_mask, View v, u32 *sa_w, u64 *e_w,
+                          u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out) {
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
-  const int low_bit = 64 - K0 * kp.w;  // >= 8
-  const u64 sym_mask = ~0ull << low_bit;
-  const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
-  DBuf<u64> kb0(c, stride), kb1(c, stride);
-  DBuf<u32> sb0(c, N), sb1(c, N);
-  u64 *keys[2] = {kb0.get(), kb1.get()};
-  u32 *vals[2] = {sb0.get(), sb1.get()};
-  int cur;
-  {
-    // round 0: the first pass rolls its keys (symbols | preceding symbol) out of the text
-    // whole digits, so that none straddles the two key words; the extra low bits are zero padding
-    const int begin_bit = low_bit & ~7;
-    int passes = (64 - begin_bit) / 8;
-    Phase ph(c, "leaf_radix_sort", (double)N * (passes * 28 - 15));
-    TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based};
-    cur = leaf_sort_text_keys(c, keys, vals, N, stride, begin_bit, tk);
-  }
-  const SplitKeys sorted_keys{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride};
-  u32 *sa = vals[cur];
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
   HIP_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(u32), c.stream));
-
-  // first active list lives in the sort's scratch buffers
-  u32 *wl_slot = (u32 *)keys[cur ^ 1];
-  u32 *wl_pos = wl_slot + N;
-  u32 *wl_grp = vals[cur ^ 1];
+  u32 *wl_slot = scratch;
+  u32 *wl_pos = scratch + N;
+  u32 *wl_grp = grp_buf;
+  DBuf<u32> wl_low_buf;
+  if (e_w) wl_low_buf = DBuf<u32>(c, N);
   u32 M;
   {
-    Phase ph(c, "leaf_group", (double)N * 16);
-    scan_generic<TieHead, TieHeadOp>(c, N, GroupIn<SplitKeys>{sorted_keys, N, sym_mask},
-                                     FirstListOut{sa, wl_slot, wl_pos, wl_grp, d_total, N});
+    Phase ph(c, "leaf_group", (double)N * (e_w ? 16 : 16));
+    scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<View>{v, N, sym_mask},
+                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, wl_low_buf.get(), d_total, N});
     M = read_u32(c, d_total);
   }
   u64 h = (u64)K0;
   int round = 0;
-  DBuf<u32> isa;
+  bool prev_follows = false;
+  DBuf<u32> isa, sa_mat;
   u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
-  if (M > 0 && (u64)M * 16 < N) {
+  if (M > 0 && (u64)M * (e_w ? 5 : 16) < N) {
     Phase ph(c, "leaf_direct_finish", (double)M * 64 * 2);
-    DBuf<u32> np(c, M);
+    DBuf<u32> src(c, M);
     u32 *d_fail = c.d_scalars + 10;
     HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
     hipLaunchKernelGGL(k_direct_finish, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos, wl_grp,
-                       M, h, np.get(), d_fail);
+                       M, h, src.get(), d_fail);
     HIP_CHECK(hipGetLastError());
     if (read_u32(c, d_fail) == 0) {
-      hipLaunchKernelGGL(k_direct_commit, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, np.get(), M, sa);
+      if (e_w) {
+        hipLaunchKernelGGL(k_direct_commit_packed, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, src.get(),
+                           wl_low_buf.get(), M, e_w);
+        prev_follows = true;
+      } else {
+        hipLaunchKernelGGL(k_direct_commit, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, src.get(), wl_pos,
+                           M, sa_w);
+      }
       HIP_CHECK(hipGetLastError());
       M = 0;
     }
+  }
+  wl_low_buf = DBuf<u32>();
+  if (M > 0 && !sa_w) {
+    // the refinement rounds rewrite positions: give the packed layout a position array of its own
+    // (tied suffixes then take their BWT symbol from the text, as in the pairs layout)
+    sa_mat = DBuf<u32>(c, N);
+    hipLaunchKernelGGL(k_unpack_pos, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, e_w, (u32)N, (u32)a,
+                       (u32)((1ull << bits_for(N - 1)) - 1), sa_mat.get());
+    HIP_CHECK(hipGetLastError());
+    sa_w = sa_mat.get();
+    set_positions(v, sa_w);
   }
   while (M > 0) {
     // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
@@ -545,7 +647,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
       if (!isa.get()) {
         h_exact = h;
         isa = DBuf<u32>(c, N);
-        hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa, (u32)a, (u32)N,
+        hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N,
                            isa.get());
         hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_pos, wl_grp, M,
                            (u32)a, isa.get());
@@ -562,7 +664,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     DBuf<u32> ns(c, M), np(c, M), ng(c, M);
     scan_generic<TieHead, TieHeadOp>(
         c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull, true},
-        RefineOut{wl_slot, cp[cc], sa, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
+        RefineOut{wl_slot, cp[cc], sa_w, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
     M = read_u32(c, d_total);
     nl_slot = std::move(ns);
     nl_pos = std::move(np);
@@ -575,32 +677,73 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, LeafEmit *E, DBuf<u32> *sa_
     if (!text_round && read_u32(c, d_overflow)) return false;
     if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
   }
-  LeafEmit em;
-  if (E) em = *E;
-  else memset(&em, 0, sizeof(em));
+  LeafEmit<View> em;
+  memset(&em, 0, sizeof(em));
+  if (E) static_cast<EmitParams &>(em) = *E;
   DBuf<u32> res;
   if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
   em.sa_out = sa_out ? res.get() : nullptr;
-  em.keys = sorted_keys;
-  em.sa = sa;
+  em.v = v;
   em.N = N;
   em.sym_mask = sym_mask;
-  em.prev_mask = 0xFFu;
+  em.prev_follows = prev_follows;
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
   {
-    Phase ph(c, "leaf_emit", (double)N * 12 + (double)(b - a) * 2);
+    Phase ph(c, "leaf_emit", (double)N * (e_w ? 8 : 12) + (double)(b - a) * 2);
     if (e == b) {
-      hipLaunchKernelGGL(k_emit_all, dim3(ceil_div(ceil_div(N, 4), 256)), dim3(256), 0, c.stream, em);
+      hipLaunchKernelGGL(k_emit_all<View>, dim3(ceil_div(ceil_div(N, 4), 256)), dim3(256), 0, c.stream, em);
       HIP_CHECK(hipGetLastError());
     } else {
-      scan_generic<u32, SumU32>(c, N, LeafFilterIn{sa, (u32)b}, LeafFilterOut{em});
+      scan_generic<u32, SumU32>(c, N, LeafFilterIn<View>{v, (u32)b}, LeafFilterOut<View>{em});
     }
   }
   if (sa_out) *sa_out = std::move(res);
   return true;
 }
 
-static void run_leaf_sort(Ctx &c, i64 a, i64 b, LeafEmit *E, DBuf<u32> *sa_out) {
+// Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
+// been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
+static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out) {
+  const u64 N = (u64)(e - a);
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
+  const KeyPlan kp = plan_keys(span, c.sym_bits, N);
+  const int K0 = kp.K0;
+  const int low_bit = 64 - K0 * kp.w;  // >= 8 (pairs), >= 32 (packed)
+  const u64 sym_mask = ~0ull << low_bit;
+  const int begin_bit = low_bit & ~7;  // whole digits; the extra low bits are zero padding
+  const int passes = (64 - begin_bit) / 8;
+  TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
+  if (kp.pbits) {
+    // packed elements; the spare buffer later holds the first active list (2N words)
+    DBuf<u64> eb0(c, N), eb1(c, N);
+    DBuf<u32> grp(c, N);
+    u64 *el[2] = {eb0.get(), eb1.get()};
+    int cur;
+    {
+      Phase ph(c, "leaf_radix_sort", (double)N * (passes * 24 - 15));
+      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk);
+    }
+    PackedView v{el[cur], nullptr, (u32)a, (u32)((1ull << kp.pbits) - 1), kp.pbits};
+    return finish_window<PackedView>(c, a, b, e, N, K0, sym_mask, v, nullptr, el[cur], (u32 *)el[cur ^ 1], grp.get(), E,
+                                     sa_out);
+  }
+  const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
+  DBuf<u64> kb0(c, stride), kb1(c, stride);
+  DBuf<u32> sb0(c, N), sb1(c, N);
+  u64 *keys[2] = {kb0.get(), kb1.get()};
+  u32 *vals[2] = {sb0.get(), sb1.get()};
+  int cur;
+  {
+    Phase ph(c, "leaf_radix_sort", (double)N * (passes * 28 - 15));
+    cur = leaf_sort_text_keys(c, keys, vals, N, stride, begin_bit, tk);
+  }
+  PairsView v{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride, vals[cur]};
+  return finish_window<PairsView>(c, a, b, e, N, K0, sym_mask, v, vals[cur], nullptr, (u32 *)keys[cur ^ 1],
+                                  vals[cur ^ 1], E, sa_out);
+}
+
+static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *sa_out) {
   if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
   if (a < 0 || b > c.n || a >= b) fail(BWT_HIP_EINVAL, "bad leaf range [%ld,%ld) for n=%ld", (long)a, (long)b, (long)c.n);
   i64 slack = 0;
@@ -657,7 +800,7 @@ Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns_req) {
     HIP_CHECK(hipMemsetAsync(sp.get(), 0xFF, (size_t)ns * 4, c.stream));
     u32 *special = c.d_scalars + 16;
     HIP_CHECK(hipMemsetAsync(special, 0xFF, 8, c.stream));
-    LeafEmit E;
+    EmitParams E;
     memset(&E, 0, sizeof(E));
     E.T = c.T;
     E.n = (u64)c.n;
