@@ -41,12 +41,15 @@ def main():
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
         lines.append("%-100s %6d %14.1f %14.1f" % (k[:100], fetch[k][1], fetch[k][0] / 1e3, write.get(k, (0, 0))[0] / 1e3))
     open(os.path.join(dst, tag + "_pmc_traffic_n1e9.txt"), "w").write("\n".join(lines) + "\n")
-    name = [k for k in fetch if "k_rs_scatter<unsigned long, true, 0, false, true>" in k][0]
+    # the leaf sort's scatter pass: packed elements (keys only) or key + position pairs, whichever the run used
+    cands = [(k, "leaf:k_rs_scatter_u64_keys") for k in fetch if "k_rs_scatter<unsigned long, false, 0, false, false>" in k]
+    cands += [(k, "leaf:k_rs_scatter_u64_pairs") for k in fetch if "k_rs_scatter<unsigned long, true, 0, false, true>" in k]
+    name, timer = cands[0]
     f_kb, n_launch = fetch[name]
     w_kb = write[name][0]
     json.dump({
         "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --steps 1 --warmup 0 --cpu_n 0 --no-timers",
-        "workload": {"n": 1000000000, "leaves": 2},
+        "workload": {"n": 1000000000, "leaves": 2}, "timer": timer,
         "kernel": name.split("(")[0], "launches": n_launch,
         "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
         "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of coalesced streaming reads as 64 B); WRITE_SIZE as is",
