@@ -9,10 +9,13 @@
 //             the fly.  Two layouts (TextKeys in internal.h): (key, position)
 //             pairs of 12 bytes, or -- small alphabets, windows below 2^29 --
 //             one 8-byte element holding codes, preceding symbol and position
+//   direct    one pass that ends the sort on texts without long repeats: a suffix
+//             whose key is unique is final; one that shares its key counts the
+//             members of its (small) group that are smaller by comparing the text
+//             itself; either way it then writes its own BWT symbol, samples and
+//             suffix array entry.  Given up as a whole when a group is large or
+//             a comparison runs long; then:
 //   tie list  suffixes whose key is shared form groups; only those stay active
-//   direct    if ties are sparse, small groups are ordered by comparing the text
-//             itself (on random text this ends the sort); given up as a whole
-//             when a group is large or a comparison runs long
 //   text rnd  active suffixes are ordered inside their group by the next K1
 //             symbols read from the text (no inverse array needed)
 //   doubling  the inverse suffix array is built once, then every round orders
@@ -55,14 +58,12 @@ struct PlainKeys {
 };
 
 // The sorted window after round 0, in either layout.  key(i): symbol codes in the top bits, the preceding
-// symbol in the low byte.  pos(i): text position.  low(i): the part of an element that moves when a tie is
-// resolved (packed layout only).  i0 of the *4 forms is a multiple of four.
+// symbol in the low byte.  pos(i): text position.  i0 of the *4 forms is a multiple of four.
 struct PairsView {
   const u32 *lo, *hi;  // key words, both 16-byte aligned
   const u32 *sa;
   __device__ __forceinline__ u64 key(size_t i) const { return ((u64)hi[i] << 32) | lo[i]; }
   __device__ __forceinline__ u32 pos(size_t i) const { return sa[i]; }
-  __device__ __forceinline__ u32 low(size_t) const { return 0; }
   __device__ __forceinline__ void key4(size_t i0, u64 (&k)[4]) const {
     const uint4 l = *reinterpret_cast<const uint4 *>(lo + i0), h = *reinterpret_cast<const uint4 *>(hi + i0);
     k[0] = ((u64)h.x << 32) | l.x;
@@ -86,7 +87,6 @@ struct PackedView {
   __device__ __forceinline__ u64 cvt(u64 x) const { return (x & 0xFFFFFFFF00000000ull) | ((u32)x >> pbits); }
   __device__ __forceinline__ u64 key(size_t i) const { return cvt(e[i]); }
   __device__ __forceinline__ u32 pos(size_t i) const { return sa ? sa[i] : a + ((u32)e[i] & posmask); }
-  __device__ __forceinline__ u32 low(size_t i) const { return (u32)e[i]; }
   __device__ __forceinline__ void raw4(size_t i0, u64 (&x)[4]) const {
     const uint4 v0 = *reinterpret_cast<const uint4 *>(e + i0), v1 = *reinterpret_cast<const uint4 *>(e + i0 + 2);
     x[0] = ((u64)v0.y << 32) | v0.x;
@@ -164,11 +164,11 @@ struct ViewTies {
   }
 };
 
-// after round 0: emit the active list (slot = rank index, pos, group = head rank; low: see View)
+// after round 0: emit the active list (slot = rank index, pos, group = head rank)
 template <class View>
 struct FirstListOut {
   View v;
-  u32 *slot, *pos, *grp, *low;  // low may be null
+  u32 *slot, *pos, *grp;
   u32 *total;
   size_t n;
   __device__ __forceinline__ void operator()(size_t i, TieHead ex, TieHead in) const {
@@ -177,7 +177,6 @@ struct FirstListOut {
       slot[k] = (u32)i;
       pos[k] = v.pos(i);
       grp[k] = in.hmax - 1;
-      if (low) low[k] = v.low(i);
     }
     if (i + 1 == n) *total = in.cnt;
   }
@@ -260,70 +259,27 @@ __global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64
 }
 
 // ----------------------------------------------------------------------------
-// direct finish for sparse, shallow ties: every tied suffix counts the members of
-// its (small) group that are smaller, comparing the text itself from depth h on.
-// All or nothing: a group of more than DF_GROUP members or a comparison longer
-// than DF_DEPTH symbols raises `fail` and the regular rounds take over.
-// Comparing the text gives the full-text order whatever the window is.
+// ties ordered by comparing the text itself, for sparse and shallow ties.  All or
+// nothing: a group of more than DF_GROUP members or a comparison longer than
+// DF_DEPTH symbols gives up and the regular rounds take over.  Comparing the
+// text gives the full-text order whatever the window is.
 // ----------------------------------------------------------------------------
 constexpr u32 DF_GROUP = 32;
 constexpr u32 DF_DEPTH = 512;
 
-__global__ void k_direct_finish(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ pos,
-                                const u32 *__restrict__ grp, u32 M, u64 h, u32 *__restrict__ out_src,
-                                u32 *__restrict__ fail) {
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M) return;
-  const u32 g = grp[k];
-  u32 lo = k, hi = k;  // group = [lo, hi]
-  while (lo > 0 && grp[lo - 1] == g && k - lo < DF_GROUP) lo--;
-  while (hi + 1 < M && grp[hi + 1] == g && hi - k < DF_GROUP) hi++;
-  if (k - lo >= DF_GROUP || hi - k >= DF_GROUP) {
-    *fail = 1;
-    return;
+// is T[y:] < T[x:] ?  (x != y)  Positions at or past n read as the empty suffix, the smallest; of two
+// exhausted suffixes the shorter is the smaller (TextKeys, zero-based coding).  *decided = false when the
+// first DF_DEPTH symbols are equal.
+__device__ __forceinline__ bool text_less(const u8 *__restrict__ T, u64 n, u64 y, u64 x, bool *decided) {
+  *decided = true;
+  for (u32 d = 0; d < DF_DEPTH; d++) {
+    const bool ey = y + d >= n, ex = x + d >= n;
+    if (ey || ex) return ey && (!ex || y > x);
+    const u32 cy = T[y + d], cx = T[x + d];
+    if (cy != cx) return cy < cx;
   }
-  const u64 x = (u64)pos[k] + h;
-  u32 smaller = 0;
-  for (u32 j = lo; j <= hi; j++) {
-    if (j == k) continue;
-    const u64 y = (u64)pos[j] + h;
-    // is T[y:] < T[x:] ?  Positions at or past n read as the empty suffix, the smallest.
-    bool less = false, decided = false;
-    for (u32 d = 0; d < DF_DEPTH; d++) {
-      const bool ey = y + d >= n, ex = x + d >= n;
-      if (ey || ex) {
-        less = ey && (!ex || y > x);  // nothing left of either: the shorter suffix is the smaller
-        decided = true;
-        break;
-      }
-      const u32 cy = T[y + d], cx = T[x + d];
-      if (cy != cx) {
-        less = cy < cx;
-        decided = true;
-        break;
-      }
-    }
-    if (!decided) {
-      *fail = 1;
-      return;
-    }
-    smaller += less;
-  }
-  out_src[lo + smaller] = k;  // list entry lo + smaller receives this suffix
-}
-
-// pairs layout: the position moves
-__global__ void k_direct_commit(const u32 *__restrict__ slot, const u32 *__restrict__ src, const u32 *__restrict__ pos,
-                                u32 M, u32 *__restrict__ sa) {
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < M) sa[slot[k]] = pos[src[k]];
-}
-
-// packed layout: the element's low word (preceding symbol and position) moves; the codes are the group's
-__global__ void k_direct_commit_packed(const u32 *__restrict__ slot, const u32 *__restrict__ src,
-                                       const u32 *__restrict__ low, u32 M, u64 *__restrict__ e) {
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < M) reinterpret_cast<u32 *>(e + slot[k])[0] = low[src[k]];
+  *decided = false;
+  return false;
 }
 
 __global__ void k_unpack_pos(const u64 *__restrict__ e, u32 N, u32 a, u32 posmask, u32 *__restrict__ sa) {
@@ -360,8 +316,9 @@ struct LeafEmit : EmitParams {
   View v;            // the sorted window
   u64 N;             // window length
   u64 sym_mask;      // symbol field of a key
-  bool prev_follows; // the preceding symbol travels with the position when ties are resolved (packed layout,
-                     // resolved by direct comparison): the key's low byte is right for tied suffixes too
+  u64 h;             // direct_tied(): depth of the round-0 keys
+  u32 leaf_end;      // direct_tied(): positions at or beyond it are window slack, not part of the leaf
+  u32 *fail;         // direct_tied(): raised when a group is too large or a comparison too long
 
   double samp_ratio; // (ns-1)/(m-1), only used to skip positions that are certainly not sampled
 
@@ -399,6 +356,51 @@ struct LeafEmit : EmitParams {
 
   __device__ __forceinline__ u8 sym_before(u32 pos) const { return pos ? T[pos - 1] : T[n - 1]; }
 
+  // the suffix at `pos` has leaf rank r and is preceded by `sym`
+  __device__ __forceinline__ void place(u64 r, u32 pos, u32 sym) const {
+    if (sa_out) sa_out[r] = pos;
+    if (L) {
+      L[r] = (u8)sym;
+      note(r, pos);
+    }
+  }
+
+  // The suffix at window rank i, whose key is shared, finds its final window rank by itself: the start of
+  // its group of equal keys plus the number of members that are smaller on the text, compared from depth h
+  // on.  Key and position belong to the same suffix, so the key's low byte is its BWT symbol wherever it
+  // ends up.  slack_before: window-slack positions at ranks below i in the order the sort left.  Raises
+  // *fail when it cannot decide: then nothing the pass has written counts.
+  __device__ __forceinline__ void direct_tied(u64 i, u32 slack_before) const {
+    if (*reinterpret_cast<volatile u32 *>(fail)) return;  // someone gave up already
+    const u64 kfull = v.key(i);
+    const u64 k = kfull & sym_mask;
+    const u32 pos = v.pos(i);
+    u64 gs = i, ge = i;
+    while (gs > 0 && i - gs < DF_GROUP && (v.key(gs - 1) & sym_mask) == k) gs--;
+    while (ge + 1 < N && ge - i < DF_GROUP && (v.key(ge + 1) & sym_mask) == k) ge++;
+    if (i - gs >= DF_GROUP || ge - i >= DF_GROUP) {
+      *fail = 1;
+      return;
+    }
+    u32 smaller = 0, slack_smaller = 0, slack_ahead = 0;
+    for (u64 j = gs; j <= ge; j++) {
+      if (j == i) continue;
+      const u32 pj = v.pos(j);
+      const bool sl = pj >= leaf_end;
+      slack_ahead += (j < i && sl);
+      bool decided;
+      const bool less = text_less(T, n, (u64)pj + h, (u64)pos + h, &decided);
+      if (!decided) {
+        *fail = 1;
+        return;
+      }
+      smaller += less;
+      slack_smaller += (less && sl);
+    }
+    if (pos >= leaf_end) return;
+    place(gs + smaller - (slack_before - slack_ahead + slack_smaller), pos, (u32)kfull & 0xFFu);
+  }
+
   // window rank i holds leaf rank r
   __device__ __forceinline__ void emit(u64 r, u64 i) const {
     u32 pos = v.pos(i);
@@ -406,7 +408,7 @@ struct LeafEmit : EmitParams {
     if (!L) return;
     u64 k = v.key(i);
     u64 top = k & sym_mask;
-    bool tied = !prev_follows && ((i > 0 && (v.key(i - 1) & sym_mask) == top) || (i + 1 < N && (v.key(i + 1) & sym_mask) == top));
+    bool tied = (i > 0 && (v.key(i - 1) & sym_mask) == top) || (i + 1 < N && (v.key(i + 1) & sym_mask) == top);
     // a suffix that round 0 placed still sits next to its key; a refined one moved, so read the text
     L[r] = tied ? sym_before(pos) : (u8)((u32)k & 0xFFu);
     note(r, pos);
@@ -416,11 +418,6 @@ struct LeafEmit : EmitParams {
   __device__ __forceinline__ void symbols4(u64 i0, const u32 (&pos)[4], u32 (&ch)[4]) const {
     u64 k[6], c[4];
     v.key4(i0, c);
-    if (prev_follows) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) ch[j] = (u32)c[j] & 0xFFu;
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < 4; j++) k[j + 1] = c[j];
     k[0] = i0 ? v.key(i0 - 1) : ~c[0];
@@ -471,6 +468,105 @@ __global__ void k_emit_all(LeafEmit<View> E) {
     E.emit4(i0);
   } else {
     for (u64 i = i0; i < E.N; i++) E.emit(i, i);
+  }
+}
+
+// One pass from the sorted window to the leaf's BWT (LeafEmit::direct_tied).  A workgroup takes DE_TILE
+// consecutive window ranks: suffixes with a unique key are emitted where they stand; the tied ones are
+// first gathered into a list in LDS and then taken one per lane, so the dependent text reads of the
+// comparisons run in full wavefronts instead of behind the few tied lanes of every wavefront.
+// SLACK: the window is longer than the leaf and leaf rank = window rank - slack positions before it;
+// tile_slack[t] = slack positions at window ranks below tile t.
+constexpr int DE_THREADS = 256;
+constexpr int DE_TILE = DE_THREADS * 4;
+
+template <class View>
+__global__ void __launch_bounds__(DE_THREADS) k_tile_slack(View v, u64 N, u32 leaf_end, u32 *__restrict__ out) {
+  __shared__ u32 scan_s[17];
+  const u64 i0 = (u64)blockIdx.x * DE_TILE + threadIdx.x * 4;
+  u32 cnt = 0;
+  if (i0 + 4 <= N) {
+    u32 p[4];
+    v.pos4(i0, p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt += p[j] >= leaf_end;
+  } else {
+    for (u64 i = i0; i < N; i++) cnt += v.pos(i) >= leaf_end;
+  }
+  u32 tot;
+  block_scan_incl<OpSum>(cnt, scan_s, &tot);
+  if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+template <class View, bool SLACK>
+__global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, const u32 *__restrict__ tile_slack) {
+  __shared__ u16 tied_list[DE_TILE];
+  __shared__ u16 slack_at[SLACK ? DE_TILE : 1];  // slack positions of the tile before each of its tied ranks
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x;
+  const u64 N = E.N;
+  const u64 base = (u64)blockIdx.x * DE_TILE;
+  const u64 i0 = base + tid * 4;
+  const bool whole = i0 + 4 <= N;
+  u64 full[4], k[6];
+  u32 pos[4];
+  if (whole) {
+    E.v.key4(i0, full);
+    E.v.pos4(i0, pos);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool ok = i0 + j < N;
+      full[j] = ok ? E.v.key(i0 + j) : 0;
+      pos[j] = ok ? E.v.pos(i0 + j) : 0;
+    }
+  }
+  // k[j + 1]: the symbols of rank i0 + j; a rank outside the window differs from its neighbours
+  k[1] = full[0] & E.sym_mask;
+  k[0] = (i0 > 0 && i0 - 1 < N) ? (E.v.key(i0 - 1) & E.sym_mask) : ~k[1];
+#pragma unroll
+  for (int j = 0; j < 4; j++) k[j + 1] = (i0 + j < N) ? (full[j] & E.sym_mask) : ~k[j];
+  k[5] = (i0 + 4 < N) ? (E.v.key(i0 + 4) & E.sym_mask) : ~k[4];
+  bool tied[4], slk[4];
+  u32 n_tied = 0, n_slack = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const bool ok = i0 + j < N;
+    tied[j] = ok && (k[j] == k[j + 1] || k[j + 1] == k[j + 2]);
+    slk[j] = SLACK && ok && pos[j] >= E.leaf_end;
+    n_tied += tied[j];
+    n_slack += slk[j];
+  }
+  const u32 mine = n_tied | (n_slack << 16);  // either count is at most DE_TILE
+  u32 tot;
+  const u32 excl = block_scan_incl<OpSum>(mine, scan_s, &tot) - mine;
+  const u32 carry = SLACK ? tile_slack[blockIdx.x] : 0u;
+  if (!SLACK && whole && n_tied == 0) {
+    if (E.sa_out) *reinterpret_cast<uint4 *>(E.sa_out + i0) = make_uint4(pos[0], pos[1], pos[2], pos[3]);
+    if (E.L) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) E.note(i0 + j, pos[j]);
+      *reinterpret_cast<u32 *>(E.L + i0) = ((u32)full[0] & 0xFFu) | (((u32)full[1] & 0xFFu) << 8) |
+                                           (((u32)full[2] & 0xFFu) << 16) | (((u32)full[3] & 0xFFu) << 24);
+    }
+  } else {
+    u32 t_at = excl & 0xFFFFu, s_at = excl >> 16;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (tied[j]) {
+        tied_list[t_at++] = (u16)(tid * 4 + j);
+        if (SLACK) slack_at[tid * 4 + j] = (u16)s_at;
+      } else if (i0 + j < N && !slk[j]) {
+        E.place(i0 + j - (carry + s_at), pos[j], (u32)full[j] & 0xFFu);
+      }
+      s_at += slk[j];
+    }
+  }
+  __syncthreads();
+  const u32 all_tied = tot & 0xFFFFu;
+  for (u32 t = tid; t < all_tied; t += DE_THREADS) {
+    const u32 at = tied_list[t];
+    E.direct_tied(base + at, SLACK ? carry + slack_at[at] : 0u);
   }
 }
 
@@ -580,48 +676,64 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
+  u32 *d_fail = c.d_scalars + 10;
   HIP_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(u32), c.stream));
+  DBuf<u32> res;
+  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
+  {
+    // First try to finish in one pass: ties ordered by direct comparison and everything emitted at once.
+    // It gives up as a whole on large tie groups or long common prefixes (repetitive texts); what it wrote
+    // until then is overwritten by the general path below.
+    Phase ph(c, "leaf_direct_emit", (double)N * (e_w ? 8 : 12) + (double)(b - a) * 2);
+    LeafEmit<View> em;
+    memset(&em, 0, sizeof(em));
+    if (E) static_cast<EmitParams &>(em) = *E;
+    em.sa_out = sa_out ? res.get() : nullptr;
+    em.v = v;
+    em.N = N;
+    em.sym_mask = sym_mask;
+    em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
+    em.h = (u64)K0;
+    em.leaf_end = (u32)b;
+    em.fail = d_fail;
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+    em.T = c.T;
+    em.n = (u64)c.n;
+    const u32 tiles = (u32)ceil_div(N, DE_TILE);
+    if (e == b) {
+      hipLaunchKernelGGL((k_direct_emit<View, false>), dim3(tiles), dim3(DE_THREADS), 0, c.stream, em,
+                         (const u32 *)nullptr);
+      HIP_CHECK(hipGetLastError());
+    } else {
+      DBuf<u32> ts(c, tiles);
+      hipLaunchKernelGGL(k_tile_slack<View>, dim3(tiles), dim3(DE_THREADS), 0, c.stream, v, N, (u32)b, ts.get());
+      HIP_CHECK(hipGetLastError());
+      scan_generic<u32, SumU32>(c, tiles, ArrayIn<u32>{ts.get()}, ArrayOutExcl<u32>{ts.get(), nullptr, tiles});
+      hipLaunchKernelGGL((k_direct_emit<View, true>), dim3(tiles), dim3(DE_THREADS), 0, c.stream, em,
+                         (const u32 *)ts.get());
+      HIP_CHECK(hipGetLastError());
+    }
+    if (read_u32(c, d_fail) == 0) {
+      if (sa_out) *sa_out = std::move(res);
+      return true;
+    }
+  }
   u32 *wl_slot = scratch;
   u32 *wl_pos = scratch + N;
   u32 *wl_grp = grp_buf;
-  DBuf<u32> wl_low_buf;
-  if (e_w) wl_low_buf = DBuf<u32>(c, N);
   u32 M;
   {
     Phase ph(c, "leaf_group", (double)N * (e_w ? 16 : 16));
     scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<View>{v, N, sym_mask},
-                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, wl_low_buf.get(), d_total, N});
+                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N});
     M = read_u32(c, d_total);
   }
   u64 h = (u64)K0;
   int round = 0;
-  bool prev_follows = false;
   DBuf<u32> isa, sa_mat;
   u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
-  if (M > 0 && (u64)M * (e_w ? 5 : 16) < N) {
-    Phase ph(c, "leaf_direct_finish", (double)M * 64 * 2);
-    DBuf<u32> src(c, M);
-    u32 *d_fail = c.d_scalars + 10;
-    HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
-    hipLaunchKernelGGL(k_direct_finish, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos, wl_grp,
-                       M, h, src.get(), d_fail);
-    HIP_CHECK(hipGetLastError());
-    if (read_u32(c, d_fail) == 0) {
-      if (e_w) {
-        hipLaunchKernelGGL(k_direct_commit_packed, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, src.get(),
-                           wl_low_buf.get(), M, e_w);
-        prev_follows = true;
-      } else {
-        hipLaunchKernelGGL(k_direct_commit, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_slot, src.get(), wl_pos,
-                           M, sa_w);
-      }
-      HIP_CHECK(hipGetLastError());
-      M = 0;
-    }
-  }
-  wl_low_buf = DBuf<u32>();
   if (M > 0 && !sa_w) {
     // the refinement rounds rewrite positions: give the packed layout a position array of its own
     // (tied suffixes then take their BWT symbol from the text, as in the pairs layout)
@@ -680,13 +792,10 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   LeafEmit<View> em;
   memset(&em, 0, sizeof(em));
   if (E) static_cast<EmitParams &>(em) = *E;
-  DBuf<u32> res;
-  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
   em.sa_out = sa_out ? res.get() : nullptr;
   em.v = v;
   em.N = N;
   em.sym_mask = sym_mask;
-  em.prev_follows = prev_follows;
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
   {
     Phase ph(c, "leaf_emit", (double)N * (e_w ? 8 : 12) + (double)(b - a) * 2);
