@@ -272,11 +272,24 @@ constexpr u32 DF_DEPTH = 512;
 // first DF_DEPTH symbols are equal.
 __device__ __forceinline__ bool text_less(const u8 *__restrict__ T, u64 n, u64 y, u64 x, bool *decided) {
   *decided = true;
-  for (u32 d = 0; d < DF_DEPTH; d++) {
-    const bool ey = y + d >= n, ex = x + d >= n;
-    if (ey || ex) return ey && (!ex || y > x);
-    const u32 cy = T[y + d], cx = T[x + d];
-    if (cy != cx) return cy < cx;
+  u32 d = 0;
+  while (d < DF_DEPTH) {
+    if (y + d + 8 <= n && x + d + 8 <= n) {  // eight symbols per (unaligned) load
+      u64 wy, wx;
+      __builtin_memcpy(&wy, T + y + d, 8);
+      __builtin_memcpy(&wx, T + x + d, 8);
+      if (wy != wx) {
+        const int at = __builtin_ctzll(wy ^ wx) & ~7;  // the first symbol is the lowest byte
+        return ((wy >> at) & 0xFFu) < ((wx >> at) & 0xFFu);
+      }
+      d += 8;
+    } else {
+      const bool ey = y + d >= n, ex = x + d >= n;
+      if (ey || ex) return ey && (!ex || y > x);
+      const u32 cy = T[y + d], cx = T[x + d];
+      if (cy != cx) return cy < cx;
+      d++;
+    }
   }
   *decided = false;
   return false;
@@ -369,15 +382,19 @@ struct LeafEmit : EmitParams {
   // its group of equal keys plus the number of members that are smaller on the text, compared from depth h
   // on.  Key and position belong to the same suffix, so the key's low byte is its BWT symbol wherever it
   // ends up.  slack_before: window-slack positions at ranks below i in the order the sort left.  Raises
-  // *fail when it cannot decide: then nothing the pass has written counts.
-  __device__ __forceinline__ void direct_tied(u64 i, u32 slack_before) const {
+  // *fail when it cannot decide: then nothing the pass has written counts.  w: key(i), pos(i) of the
+  // window, from wherever they are at hand.
+  // (One thread per group, which reads each member's text once instead of once per comparison, is slower:
+  // the pass waits on the latency of these reads, not on their number.)
+  template <class Window>
+  __device__ __forceinline__ void direct_tied(const Window &w, u64 i, u32 slack_before) const {
     if (*reinterpret_cast<volatile u32 *>(fail)) return;  // someone gave up already
-    const u64 kfull = v.key(i);
+    const u64 kfull = w.key(i);
     const u64 k = kfull & sym_mask;
-    const u32 pos = v.pos(i);
+    const u32 pos = w.pos(i);
     u64 gs = i, ge = i;
-    while (gs > 0 && i - gs < DF_GROUP && (v.key(gs - 1) & sym_mask) == k) gs--;
-    while (ge + 1 < N && ge - i < DF_GROUP && (v.key(ge + 1) & sym_mask) == k) ge++;
+    while (gs > 0 && i - gs < DF_GROUP && (w.key(gs - 1) & sym_mask) == k) gs--;
+    while (ge + 1 < N && ge - i < DF_GROUP && (w.key(ge + 1) & sym_mask) == k) ge++;
     if (i - gs >= DF_GROUP || ge - i >= DF_GROUP) {
       *fail = 1;
       return;
@@ -385,7 +402,7 @@ struct LeafEmit : EmitParams {
     u32 smaller = 0, slack_smaller = 0, slack_ahead = 0;
     for (u64 j = gs; j <= ge; j++) {
       if (j == i) continue;
-      const u32 pj = v.pos(j);
+      const u32 pj = w.pos(j);
       const bool sl = pj >= leaf_end;
       slack_ahead += (j < i && sl);
       bool decided;
@@ -473,8 +490,8 @@ __global__ void k_emit_all(LeafEmit<View> E) {
 
 // One pass from the sorted window to the leaf's BWT (LeafEmit::direct_tied).  A workgroup takes DE_TILE
 // consecutive window ranks: suffixes with a unique key are emitted where they stand; the tied ones are
-// first gathered into a list in LDS and then taken one per lane, so the dependent text reads of the
-// comparisons run in full wavefronts instead of behind the few tied lanes of every wavefront.
+// gathered into a list in LDS and then taken one per lane, so the dependent text reads of the comparisons
+// run in full wavefronts instead of behind the few tied lanes of every wavefront.
 // SLACK: the window is longer than the leaf and leaf rank = window rank - slack positions before it;
 // tile_slack[t] = slack positions at window ranks below tile t.
 constexpr int DE_THREADS = 256;
@@ -498,8 +515,21 @@ __global__ void __launch_bounds__(DE_THREADS) k_tile_slack(View v, u64 N, u32 le
   if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
+// a tile's keys and positions in LDS, the rest of the window from memory
+template <class View>
+struct TileWindow {
+  const View &v;
+  const u64 *keys;
+  const u32 *poss;
+  u64 base;
+  __device__ __forceinline__ u64 key(u64 i) const { return i - base < (u64)DE_TILE ? keys[i - base] : v.key(i); }
+  __device__ __forceinline__ u32 pos(u64 i) const { return i - base < (u64)DE_TILE ? poss[i - base] : v.pos(i); }
+};
+
 template <class View, bool SLACK>
 __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, const u32 *__restrict__ tile_slack) {
+  __shared__ __align__(16) u64 tile_key[DE_TILE];
+  __shared__ __align__(16) u32 tile_pos[DE_TILE];
   __shared__ u16 tied_list[DE_TILE];
   __shared__ u16 slack_at[SLACK ? DE_TILE : 1];  // slack positions of the tile before each of its tied ranks
   __shared__ u32 scan_s[17];
@@ -521,12 +551,18 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
       pos[j] = ok ? E.v.pos(i0 + j) : 0;
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {  // ranks beyond the window are never looked at
+    tile_key[tid * 4 + j] = full[j];
+    tile_pos[tid * 4 + j] = pos[j];
+  }
+  __syncthreads();
   // k[j + 1]: the symbols of rank i0 + j; a rank outside the window differs from its neighbours
   k[1] = full[0] & E.sym_mask;
-  k[0] = (i0 > 0 && i0 - 1 < N) ? (E.v.key(i0 - 1) & E.sym_mask) : ~k[1];
+  k[0] = (i0 > 0 && i0 - 1 < N) ? ((tid > 0 ? tile_key[tid * 4 - 1] : E.v.key(i0 - 1)) & E.sym_mask) : ~k[1];
 #pragma unroll
   for (int j = 0; j < 4; j++) k[j + 1] = (i0 + j < N) ? (full[j] & E.sym_mask) : ~k[j];
-  k[5] = (i0 + 4 < N) ? (E.v.key(i0 + 4) & E.sym_mask) : ~k[4];
+  k[5] = (i0 + 4 < N) ? ((tid + 1 < DE_THREADS ? tile_key[tid * 4 + 4] : E.v.key(i0 + 4)) & E.sym_mask) : ~k[4];
   bool tied[4], slk[4];
   u32 n_tied = 0, n_slack = 0;
 #pragma unroll
@@ -566,7 +602,7 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
   const u32 all_tied = tot & 0xFFFFu;
   for (u32 t = tid; t < all_tied; t += DE_THREADS) {
     const u32 at = tied_list[t];
-    E.direct_tied(base + at, SLACK ? carry + slack_at[at] : 0u);
+    E.direct_tied(TileWindow<View>{E.v, tile_key, tile_pos, base}, base + at, SLACK ? carry + slack_at[at] : 0u);
   }
 }
 
