@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P, u32 H) 
         g[c] = kk[c];
       }
       // the last chain may be short: its tail gets a value above every valid g
-      if (valid[c]) P.g[(u64)step * P.n_chains + chain[c]] = act[c] ? g[c] : P.m + 1;
+      if (valid[c]) __builtin_nontemporal_store(act[c] ? g[c] : P.m + 1, &P.g[(u64)step * P.n_chains + chain[c]]);
     }
   }
 }

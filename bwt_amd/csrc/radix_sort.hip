@@ -26,12 +26,12 @@
 
 namespace bwtamd {
 
-constexpr int RS_THREADS = 512;
+constexpr int RS_THREADS = 1024;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES; // 512 consecutive keys per wave
-constexpr int RH_THREADS = 256;                 // histogram kernel: 256 threads x 16 keys
+constexpr int RH_THREADS = 512;                 // histogram kernel: 512 threads x 16 keys
 constexpr int RH_ITEMS = RS_TILE / RH_THREADS;
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  This
@@ -90,6 +90,38 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
   const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
+  if (w == 2 && !tk.one_based && K0 + ITEMS <= 32) {
+    // Four symbols with 2-bit codes: four symbols per step.  Subtracting min_sym from every byte leaves
+    // 0..3 in each; one multiplication gathers the four 2-bit fields, first symbol highest, in bits
+    // 24..31 (the partial products land on distinct bits, so nothing carries).  A word with a zero byte
+    // (the terminator or beyond the text) takes the byte loop below.
+    constexpr int WORDS = (ITEMS + 32 + 3) / 4;
+    const int words = (K0 + ITEMS + 3) / 4;
+    u64 codes = 0;  // 4 * words symbols, first symbol highest
+    u32 wds[WORDS / 2 + 1];
+    bool plain = true;
+#pragma unroll
+    for (int q = 0; q < WORDS; q++) {
+      if (q < words) {
+        const u32 x = src[q];
+        if (q < WORDS / 2 + 1) wds[q] = x;
+        plain = plain && !((x - 0x01010101u) & ~x & 0x80808080u);
+        const u32 y = x - tk.min_sym * 0x01010101u;
+        codes = (codes << 8) | (((y & 0x03030303u) * 0x40100401u) >> 24);
+      }
+    }
+    if (plain) {
+      const u32 before = src[-1] >> 24;
+      const int top = 8 * words;  // bits in `codes`
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const u64 field = (codes >> (top - used - 2 * j)) & maskall;
+        const u32 prev = j == 0 ? before : (wds[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu;
+        key_out[j] = (field << lsh) | prev;
+      }
+      return;
+    }
+  }
   u64 sf = 0;
   u32 wd = 0;
   for (int k = 0; k < K0; k++) {
@@ -133,10 +165,12 @@ __global__ void __launch_bounds__(RH_THREADS)
       if (tile0 + tid * RH_ITEMS + r < n) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
-    u32 tot = 0;
+    if (tid < 256) {
+      u32 tot = 0;
 #pragma unroll
-    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-    counts[(size_t)tid * nblk + (nblk - 1 - tile)] = tot;  // tiles in reverse: this pass is reverse-stable
+      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
+      counts[(size_t)tid * nblk + (nblk - 1 - tile)] = tot;  // tiles in reverse: this pass is reverse-stable
+    }
     return;
   }
   K key[RH_ITEMS];
@@ -172,10 +206,12 @@ __global__ void __launch_bounds__(RH_THREADS)
     if (valid) atomicAdd(&cnt[w][d], 1u);  // LDS counter of this wave; order is irrelevant for a count
   }
   __syncthreads();
-  u32 tot = 0;
+  if (tid < 256) {
+    u32 tot = 0;
 #pragma unroll
-  for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-  counts[(size_t)tid * nblk + tile] = tot;
+    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
+    counts[(size_t)tid * nblk + tile] = tot;
+  }
 }
 
 template <class K>
@@ -290,7 +326,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
 // SPLIT: a 64-bit key lives as two 32-bit words `stride` words apart (all low words, then all high
 // words), so that a histogram pass reads only the half that holds its digit.
 template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT>
-__global__ void __launch_bounds__(RS_THREADS, 6)
+__global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 : 8)
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
                  u32 nblk, TextKeys tk, u32 stride) {
@@ -300,7 +336,7 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
   // the tile's keys and values in digit order.
   constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
   constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
-  constexpr size_t TEXT_BYTES = TEXT ? (size_t)RS_THREADS * (RS_ITEMS + 1) * 8 + TK_STAGE_WORDS * 4 : 0;  // key exchange + staged text
+  constexpr size_t TEXT_BYTES = TEXT ? (size_t)RS_TILE * 8 + TK_STAGE_WORDS * 4 : 0;  // key exchange + staged text
   constexpr size_t BUF0 = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
   constexpr size_t BUF_BYTES = BUF0 > TEXT_BYTES ? BUF0 : TEXT_BYTES;
   __shared__ __align__(16) unsigned char buf[BUF_BYTES];
@@ -318,10 +354,12 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
   const u32 wbase = w * RS_PER_WAVE;
   if constexpr (TEXT) {
     // The same buffer first holds the staged text (behind the key exchange area) and the keys that
-    // thread t rolled for tile indices 8t .. 8t+7, 9 words apart per thread against bank conflicts;
-    // every thread then picks up the keys of its ranking slots.
+    // thread t rolled for tile indices 8t .. 8t+7; every thread then picks up the keys of its ranking
+    // slots.  Thread t keeps key j in slot j ^ (t/4 mod 8) of its eight: 32 neighbouring threads then
+    // write to 32 different bank pairs, and the readers' 64 consecutive indices stay 64 distinct slots.
     static_assert(sizeof(K) == 8 && !(SPLIT && !HAS_VALS), "text keys: 64-bit with a position, or packed elements");
-    constexpr u32 EX_WORDS = RS_THREADS * (RS_ITEMS + 1);
+    static_assert(RS_ITEMS == 8, "slot swizzle of the key exchange");
+    constexpr u32 EX_WORDS = RS_TILE;
     static_assert(EX_WORDS * 8 + TK_STAGE_WORDS * 4 <= BUF_BYTES, "exchange area and staged text share the buffer");
     K *ex = reinterpret_cast<K *>(buf);
     u32 *stage = reinterpret_cast<u32 *>(buf + EX_WORDS * 8);
@@ -330,14 +368,14 @@ __global__ void __launch_bounds__(RS_THREADS, 6)
     u64 mine[RS_ITEMS];
     tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) ex[tid * (RS_ITEMS + 1) + j] = mine[j];
+    for (int j = 0; j < RS_ITEMS; j++) ex[tid * RS_ITEMS + (j ^ ((tid >> 2) & 7))] = mine[j];
     __syncthreads();
     const u32 pos0 = (u32)(tk.a + tile0);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
       u32 idx = wbase + r * 64 + lane;
       bool valid = idx < tile_n;
-      u64 k = valid ? ex[(idx / RS_ITEMS) * (RS_ITEMS + 1) + (idx % RS_ITEMS)] : 0ull;
+      u64 k = valid ? ex[(idx & ~7u) | ((idx & 7) ^ ((idx >> 5) & 7))] : 0ull;
       if constexpr (HAS_VALS) {
         key[r] = (K)k;
         val[r] = pos0 + idx;
