@@ -62,6 +62,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIP_CHECK(hipHostMalloc((void **)&c.h_scalars, 64 * sizeof(u32), hipHostMallocDefault));
   HIP_CHECK(hipMalloc((void **)&c.d_scalars, 64 * sizeof(u32)));
+  if (const char *v = getenv("BWT_HIP_BUCKET_MIN_N")) c.bucket_min_n = strtoull(v, nullptr, 10);  // tuning and tests
   *out = h.release();
   API_END
 }

@@ -76,6 +76,9 @@ struct Ctx {
   // phase timing (hipEvent pairs on `stream`), enabled by timing_level > 0
   int timing_level = 0;
   const char *sort_tag = "";  // prefix of the radix sort's per-kernel timer names (who is sorting)
+  // leaf windows of at least this many suffixes may take the bucket route of the leaf sort (two passes
+  // on the top 16 key bits, the rest in LDS); below it the 65536 buckets are too small to pay
+  u64 bucket_min_n = 1ull << 26;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;

@@ -537,6 +537,148 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
   return cur;
 }
 
+// ----------------------------------------------------------------------------
+// Bucket route for 8-byte elements with 32 sorted key bits: after two passes on the top 16 bits the
+// elements with the same top 16 bits (a bucket) are contiguous; one workgroup loads a bucket, sorts it on
+// the other bits with one or two ranking rounds in LDS and writes it back in place.  The result is the one
+// four stable passes give, for half the trips through memory of the last two.  Needs every bucket to
+// fit a workgroup (BK_CAP elements): texts with a skewed distribution of 8-symbol words take the passes.
+// ----------------------------------------------------------------------------
+constexpr int BK_THREADS = 1024;
+constexpr int BK_WAVES = BK_THREADS / 64;
+constexpr int BK_ITEMS = 9;
+constexpr int BK_CAP = BK_THREADS * BK_ITEMS;  // 9216 elements = 72 KB of LDS
+constexpr int BK_PER_WAVE = 64 * BK_ITEMS;
+constexpr u32 BK_BUCKETS = 1u << 16;
+
+// start[k] = number of elements whose top 16 bits are below k, k = 0 .. 65536 (e is sorted on them)
+__global__ void k_bucket_bounds(const u64 *__restrict__ e, u32 n, u32 *__restrict__ start) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > BK_BUCKETS) return;
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if ((u32)(e[mid] >> 48) < k) lo = mid + 1;
+    else hi = mid;
+  }
+  start[k] = lo;
+}
+
+__global__ void k_bucket_max(const u32 *__restrict__ start, u32 *__restrict__ out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 v = k < BK_BUCKETS ? start[k + 1] - start[k] : 0u;
+  v = wave_reduce_max(v);
+  if (lane_id() == 0) atomicMax(out, v);
+}
+
+// Stable rank of the workgroup's `cnt` keys by the digit at `shift`.  Wave w holds the keys at indices
+// w * BK_PER_WAVE + r * 64 + lane in key[r]; pos[r] receives each key's index in digit order.
+// ctr: (BK_WAVES + 1) rows of 256 counters, dead when the function returns.
+__device__ __forceinline__ void bk_rank(const u64 (&key)[BK_ITEMS], int shift, u32 cnt, u32 (*ctr)[256], u32 *scan_s,
+                                        u32 (&pos)[BK_ITEMS]) {
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 wbase = w * BK_PER_WAVE;
+  u32 *myc = ctr[w];
+  u32 *dstart = ctr[BK_WAVES];
+  for (u32 d = lane; d < 256; d += 64) myc[d] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  u32 dig[BK_ITEMS];
+#pragma unroll
+  for (int r = 0; r < BK_ITEMS; r++) {
+    dig[r] = (u32)(key[r] >> shift) & 255u;
+    pos[r] = 0;
+    if (wbase + r * 64 < cnt) {  // the same for the whole wave
+      const bool valid = wbase + r * 64 + lane < cnt;
+      const u64 v = __ballot(valid);
+      u32 lo = (u32)v, hi = (u32)(v >> 32);
+      match_digit8(dig[r], lo, hi);
+      const u32 before = count_below_lane(lo, hi);
+      const u32 base = __hip_atomic_load(&myc[dig[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (valid && before == 0)
+        __hip_atomic_fetch_add(&myc[dig[r]], (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      pos[r] = base + before;
+    }
+  }
+  lds_barrier();
+  u32 tot = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int k = 0; k < BK_WAVES; k++) {
+      const u32 v = ctr[k][tid];
+      ctr[k][tid] = tot;
+      tot += v;
+    }
+  }
+  u32 incl = wave_scan_incl_sum(tot);
+  if (lane == 63 && w < 4) scan_s[w] = incl;
+  lds_barrier();
+  for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
+  if (tid < 256) dstart[tid] = incl - tot;
+  lds_barrier();
+#pragma unroll
+  for (int r = 0; r < BK_ITEMS; r++) pos[r] += dstart[dig[r]] + myc[dig[r]];
+  lds_barrier();  // the counters are dead from here
+}
+
+__global__ void __launch_bounds__(BK_THREADS) k_bucket_sort(u64 *__restrict__ e, const u32 *__restrict__ start, int begin_bit) {
+  // the bucket's elements in digit order; the ranking counters use the same memory while the keys are in registers
+  __shared__ __align__(16) u64 buf[BK_CAP];
+  __shared__ u32 scan_s[4];
+  static_assert(sizeof(u64) * BK_CAP >= (BK_WAVES + 1) * 256 * 4, "counters fit the staging area");
+  const u32 s = start[blockIdx.x], cnt = start[blockIdx.x + 1] - s;  // cnt <= BK_CAP: the caller has checked
+  if (cnt < 2) return;
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 wbase = w * BK_PER_WAVE;
+  u64 *mine = e + s;
+  u32(*ctr)[256] = reinterpret_cast<u32(*)[256]>(buf);
+  u64 key[BK_ITEMS];
+  u32 pos[BK_ITEMS];
+#pragma unroll
+  for (int r = 0; r < BK_ITEMS; r++) {
+    const u32 idx = wbase + r * 64 + lane;
+    key[r] = idx < cnt ? mine[idx] : 0ull;
+  }
+#pragma unroll 1
+  for (int shift = begin_bit; shift < 48; shift += 8) {
+    bk_rank(key, shift, cnt, ctr, scan_s, pos);
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++)
+      if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
+    lds_barrier();
+    if (shift + 8 < 48) {
+#pragma unroll
+      for (int r = 0; r < BK_ITEMS; r++) {
+        const u32 idx = wbase + r * 64 + lane;
+        key[r] = idx < cnt ? buf[idx] : 0ull;
+      }
+      lds_barrier();  // the next round's counters overwrite the buffer
+    }
+  }
+  for (u32 i = tid; i < cnt; i += BK_THREADS) mine[i] = buf[i];
+}
+
+// Sorts e (already sorted on its top 16 bits) on bits begin_bit..47 inside every bucket.  False if some
+// bucket does not fit a workgroup: nothing has been changed then.
+static bool bucket_sort_low(Ctx &c, u64 *e, size_t n, int begin_bit) {
+  DBuf<u32> start(c, BK_BUCKETS + 1);
+  u32 *d_max = c.d_scalars + 12;
+  {
+    KernelTimer kt(c, "leaf:k_bucket_bounds", (double)BK_BUCKETS * 8 * 29);
+    HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(BK_BUCKETS / 256 + 1), dim3(256), 0, c.stream, e, (u32)n, start.get());
+    hipLaunchKernelGGL(k_bucket_max, dim3(BK_BUCKETS / 256), dim3(256), 0, c.stream, start.get(), d_max);
+    HIP_CHECK(hipGetLastError());
+  }
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  if (c.h_scalars[0] > (u32)BK_CAP) return false;
+  KernelTimer kt(c, "leaf:k_bucket_sort", (double)n * 16);
+  hipLaunchKernelGGL(k_bucket_sort, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, e, start.get(), begin_bit);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // Round 0 with packed elements (TextKeys::pbits != 0): the first pass builds the elements from the text
 // (reverse-stable, see TextKeys), the others are plain stable passes over 8-byte keys without values.
 int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text) {
@@ -544,6 +686,11 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
   if (begin_bit % 8 != 0 || begin_bit < 32 || begin_bit >= 64 || text.pbits <= 0 || text.pbits > 31 ||
       (n - 1) >> text.pbits)
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad packed layout (begin_bit %d, pbits %d, n %zu)", begin_bit, text.pbits, n);
+  if (begin_bit < 48 && n >= c.bucket_min_n) {
+    // top 16 bits by two passes (the first one reverse-stable from the text, as always), the rest per bucket
+    const int cur = leaf_sort_text_packed(c, elems, n, 48, text);
+    if (bucket_sort_low(c, elems[cur], n, begin_bit)) return cur;
+  }
   u32 nblk = ceil_div(n, RS_TILE);
   DBuf<u32> counts(c, (size_t)256 * nblk);
   TextKeys none;

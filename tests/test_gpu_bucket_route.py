@@ -1,0 +1,18 @@
+"""The leaf sort's bucket route (two passes on the top 16 key bits, the rest per bucket in LDS) only pays on windows of
+tens of millions of suffixes; here its threshold is lowered so that small texts take it, in a process of its own."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_bucket_route_on_small_texts():
+    env = dict(os.environ, BWT_HIP_BUCKET_MIN_N="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "bucket_route_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "bucket route ok" in r.stdout
