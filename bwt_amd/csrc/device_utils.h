@@ -112,4 +112,10 @@ __device__ __forceinline__ u32 count_below_lane(u32 lo, u32 hi) {
   return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
 }
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding
+// global access of the wave).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 }  // namespace bwtamd

@@ -194,7 +194,15 @@ int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride, int begin_bit,
                         const TextKeys &text);
 // The same for packed elements (text.pbits != 0): sorts them on bits [begin_bit, 64), begin_bit >= 32.
-int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text);
+// Bucket route of the packed leaf sort, handed from the sort to whoever finishes the buckets: elements sorted on
+// their top 16 key bits, start[k] = first element of bucket k (65537 entries), bits begin_bit..47 still unsorted.
+struct BucketState {
+  DBuf<u32> start;
+  int begin_bit = 0;
+  bool pending = false;
+};
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs);
+void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "device_utils.h"
+#include "bucket_rank.h"
 #include "internal.h"
 
 namespace bwtamd {
@@ -219,15 +220,10 @@ __device__ __forceinline__ u32 digit_of(K key, int shift, u32 mask) {
   return (u32)(key >> shift) & mask;
 }
 
-// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding
-// global access of the wave).  Tried on top of it and dropped: a persistent variant that loops over tiles
-// and issues the next tile's loads while the current one is written out -- 80 registers do not hold both
-// tiles' state (spills), and at 2 workgroups per CU it was 50 % slower than one tile per workgroup.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // Ranking, ordering in LDS and writing of one tile.  FULL: the tile has all RS_TILE keys.
+// Tried and dropped: a persistent variant that loops over tiles and issues the next tile's loads while the
+// current one is written out -- 80 registers do not hold both tiles' state (spills), and at 2 workgroups
+// per CU it was 50 % slower than one tile per workgroup.
 // REVERSE: equal digits leave in the reverse of their input order, over the whole array (the caller's
 // histogram is then laid out with the tiles in reverse, see k_rs_hist).
 template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE>
@@ -544,13 +540,6 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
 // four stable passes give, for half the trips through memory of the last two.  Needs every bucket to
 // fit a workgroup (BK_CAP elements): texts with a skewed distribution of 8-symbol words take the passes.
 // ----------------------------------------------------------------------------
-constexpr int BK_THREADS = 1024;
-constexpr int BK_WAVES = BK_THREADS / 64;
-constexpr int BK_ITEMS = 9;
-constexpr int BK_CAP = BK_THREADS * BK_ITEMS;  // 9216 elements = 72 KB of LDS
-constexpr int BK_PER_WAVE = 64 * BK_ITEMS;
-constexpr u32 BK_BUCKETS = 1u << 16;
-
 // start[k] = number of elements whose top 16 bits are below k, k = 0 .. 65536 (e is sorted on them)
 __global__ void k_bucket_bounds(const u64 *__restrict__ e, u32 n, u32 *__restrict__ start) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,56 +558,6 @@ __global__ void k_bucket_max(const u32 *__restrict__ start, u32 *__restrict__ ou
   u32 v = k < BK_BUCKETS ? start[k + 1] - start[k] : 0u;
   v = wave_reduce_max(v);
   if (lane_id() == 0) atomicMax(out, v);
-}
-
-// Stable rank of the workgroup's `cnt` keys by the digit at `shift`.  Wave w holds the keys at indices
-// w * BK_PER_WAVE + r * 64 + lane in key[r]; pos[r] receives each key's index in digit order.
-// ctr: (BK_WAVES + 1) rows of 256 counters, dead when the function returns.
-__device__ __forceinline__ void bk_rank(const u64 (&key)[BK_ITEMS], int shift, u32 cnt, u32 (*ctr)[256], u32 *scan_s,
-                                        u32 (&pos)[BK_ITEMS]) {
-  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 wbase = w * BK_PER_WAVE;
-  u32 *myc = ctr[w];
-  u32 *dstart = ctr[BK_WAVES];
-  for (u32 d = lane; d < 256; d += 64) myc[d] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  u32 dig[BK_ITEMS];
-#pragma unroll
-  for (int r = 0; r < BK_ITEMS; r++) {
-    dig[r] = (u32)(key[r] >> shift) & 255u;
-    pos[r] = 0;
-    if (wbase + r * 64 < cnt) {  // the same for the whole wave
-      const bool valid = wbase + r * 64 + lane < cnt;
-      const u64 v = __ballot(valid);
-      u32 lo = (u32)v, hi = (u32)(v >> 32);
-      match_digit8(dig[r], lo, hi);
-      const u32 before = count_below_lane(lo, hi);
-      const u32 base = __hip_atomic_load(&myc[dig[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (valid && before == 0)
-        __hip_atomic_fetch_add(&myc[dig[r]], (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      pos[r] = base + before;
-    }
-  }
-  lds_barrier();
-  u32 tot = 0;
-  if (tid < 256) {
-#pragma unroll
-    for (int k = 0; k < BK_WAVES; k++) {
-      const u32 v = ctr[k][tid];
-      ctr[k][tid] = tot;
-      tot += v;
-    }
-  }
-  u32 incl = wave_scan_incl_sum(tot);
-  if (lane == 63 && w < 4) scan_s[w] = incl;
-  lds_barrier();
-  for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
-  if (tid < 256) dstart[tid] = incl - tot;
-  lds_barrier();
-#pragma unroll
-  for (int r = 0; r < BK_ITEMS; r++) pos[r] += dstart[dig[r]] + myc[dig[r]];
-  lds_barrier();  // the counters are dead from here
 }
 
 __global__ void __launch_bounds__(BK_THREADS) k_bucket_sort(u64 *__restrict__ e, const u32 *__restrict__ start, int begin_bit) {
@@ -658,10 +597,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_sort(u64 *__restrict__ e,
   for (u32 i = tid; i < cnt; i += BK_THREADS) mine[i] = buf[i];
 }
 
-// Sorts e (already sorted on its top 16 bits) on bits begin_bit..47 inside every bucket.  False if some
-// bucket does not fit a workgroup: nothing has been changed then.
-static bool bucket_sort_low(Ctx &c, u64 *e, size_t n, int begin_bit) {
-  DBuf<u32> start(c, BK_BUCKETS + 1);
+// Bucket bounds of e (already sorted on its top 16 bits).  False if some bucket does not fit a workgroup.
+static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start) {
+  start = DBuf<u32>(c, BK_BUCKETS + 1);
   u32 *d_max = c.d_scalars + 12;
   {
     KernelTimer kt(c, "leaf:k_bucket_bounds", (double)BK_BUCKETS * 8 * 29);
@@ -672,24 +610,38 @@ static bool bucket_sort_low(Ctx &c, u64 *e, size_t n, int begin_bit) {
   }
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();
-  if (c.h_scalars[0] > (u32)BK_CAP) return false;
+  return c.h_scalars[0] <= (u32)BK_CAP;
+}
+
+// sorts every bucket of e on bits begin_bit..47, in place
+void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs) {
   KernelTimer kt(c, "leaf:k_bucket_sort", (double)n * 16);
-  hipLaunchKernelGGL(k_bucket_sort, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, e, start.get(), begin_bit);
+  hipLaunchKernelGGL(k_bucket_sort, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, e, bs.start.get(), bs.begin_bit);
   HIP_CHECK(hipGetLastError());
-  return true;
 }
 
 // Round 0 with packed elements (TextKeys::pbits != 0): the first pass builds the elements from the text
 // (reverse-stable, see TextKeys), the others are plain stable passes over 8-byte keys without values.
-int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text) {
+// bs: if not null and the bucket route applies, the sort stops after the passes on the top 16 bits and
+// hands the buckets over (bs->pending); the caller finishes them (bucket_sort_in_place, or a kernel of its
+// own that consumes the sorted buckets straight from LDS).
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs) {
   if (n == 0) return 0;
   if (begin_bit % 8 != 0 || begin_bit < 32 || begin_bit >= 64 || text.pbits <= 0 || text.pbits > 31 ||
       (n - 1) >> text.pbits)
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad packed layout (begin_bit %d, pbits %d, n %zu)", begin_bit, text.pbits, n);
   if (begin_bit < 48 && n >= c.bucket_min_n) {
     // top 16 bits by two passes (the first one reverse-stable from the text, as always), the rest per bucket
-    const int cur = leaf_sort_text_packed(c, elems, n, 48, text);
-    if (bucket_sort_low(c, elems[cur], n, begin_bit)) return cur;
+    const int cur = leaf_sort_text_packed(c, elems, n, 48, text, nullptr);
+    BucketState local;
+    BucketState &st = bs ? *bs : local;
+    if (bucket_bounds(c, elems[cur], n, st.start)) {
+      st.begin_bit = begin_bit;
+      st.pending = true;
+      if (!bs) bucket_sort_in_place(c, elems[cur], n, st);
+      return cur;
+    }
+    st.start = DBuf<u32>();
   }
   u32 nblk = ceil_div(n, RS_TILE);
   DBuf<u32> counts(c, (size_t)256 * nblk);

@@ -31,6 +31,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
+#include "bucket_rank.h"
 #include "device_utils.h"
 #include "internal.h"
 #include "scan_tmpl.h"
@@ -606,6 +609,178 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
   }
 }
 
+// ----------------------------------------------------------------------------
+// Bucket route (packed layout): the radix passes have stopped after the top 16 key bits.  One workgroup
+// loads a bucket, ranks it on the remaining key bits in LDS (bk_rank) and, instead of writing the sorted
+// bucket back for k_direct_emit to read it again, does that kernel's work straight from LDS: unique keys
+// are emitted where they stand, tied ones by LeafEmit::direct_tied.  Groups of equal keys never straddle
+// buckets.  slack_before[k] = window-slack positions in the buckets below k.
+// ----------------------------------------------------------------------------
+struct BucketWindow {  // the bucket from LDS, anything else (never a match) from memory
+  const PackedView &v;
+  const u64 *buf;
+  u64 s;
+  u32 cnt;
+  __device__ __forceinline__ u64 key(u64 i) const { return i - s < (u64)cnt ? v.cvt(buf[i - s]) : v.key(i); }
+  __device__ __forceinline__ u32 pos(u64 i) const {
+    return i - s < (u64)cnt ? v.a + ((u32)buf[i - s] & v.posmask) : v.pos(i);
+  }
+};
+
+// index of the k-th set bit of m (k below its population count)
+__device__ __forceinline__ u32 select_bit(u64 m, u32 k) {
+  u32 word = (u32)m, base = 0;
+  const u32 c = __popc(word);
+  if (k >= c) {
+    k -= c;
+    word = (u32)(m >> 32);
+    base = 32;
+  }
+#pragma unroll
+  for (int h = 16; h > 0; h >>= 1) {
+    const u32 low = word & ((1u << h) - 1);
+    const u32 cl = __popc(low);
+    if (k >= cl) {
+      k -= cl;
+      word >>= h;
+      base += h;
+    } else {
+      word = low;
+    }
+  }
+  return base;
+}
+
+constexpr int BK_MASKS = BK_ITEMS * BK_WAVES;  // one 64-bit flag word per wave and round
+
+template <bool SLACK>
+__global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
+    k_bucket_emit(LeafEmit<PackedView> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before,
+                  int begin_bit) {
+  __shared__ __align__(16) u64 buf[BK_CAP];
+  __shared__ u64 tied_mask[BK_MASKS], slack_mask[SLACK ? BK_MASKS : 1];
+  __shared__ u32 tied_pre[BK_MASKS + 1], slack_pre[SLACK ? BK_MASKS : 1];
+  __shared__ u32 scan_s[4];
+  static_assert(BK_MASKS <= 256, "the flag words are scanned by the first four waves");
+  const u32 s = start[blockIdx.x], cnt = start[blockIdx.x + 1] - s;  // cnt <= BK_CAP: the caller has checked
+  if (cnt == 0) return;
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 wbase = w * BK_PER_WAVE;
+  const u64 *mine = E.v.e + s;
+  {
+    u32(*ctr)[256] = reinterpret_cast<u32(*)[256]>(buf);
+    u64 key[BK_ITEMS];
+    u32 pos[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {
+      const u32 idx = wbase + r * 64 + lane;
+      key[r] = idx < cnt ? mine[idx] : 0ull;
+      pos[r] = idx;
+    }
+#pragma unroll 1
+    for (int shift = begin_bit; shift < 48; shift += 8) {
+      bk_rank(key, shift, cnt, ctr, scan_s, pos);
+#pragma unroll
+      for (int r = 0; r < BK_ITEMS; r++)
+        if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
+      lds_barrier();
+      if (shift + 8 < 48) {
+#pragma unroll
+        for (int r = 0; r < BK_ITEMS; r++) {
+          const u32 idx = wbase + r * 64 + lane;
+          key[r] = idx < cnt ? buf[idx] : 0ull;
+        }
+        lds_barrier();  // the next round's counters overwrite the buffer
+      }
+    }
+    if (begin_bit >= 48) {  // nothing left to sort on
+#pragma unroll
+      for (int r = 0; r < BK_ITEMS; r++)
+        if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
+      lds_barrier();
+    }
+  }
+  // flags: thread t looks at the sorted indices r * 1024 + t, so flag word r * 16 + w covers 64 consecutive ones
+  const u64 sym_mask = E.sym_mask;  // its low word is zero: raw elements compare like keys
+  u32 tied_bits = 0, slack_bits = 0;
+#pragma unroll
+  for (int r = 0; r < BK_ITEMS; r++) {
+    const u32 idx = r * BK_THREADS + tid;
+    bool tied = false, sl = false;
+    if (idx < cnt) {
+      const u64 me = buf[idx];
+      const u64 km = me & sym_mask;
+      tied = (idx > 0 && (buf[idx - 1] & sym_mask) == km) || (idx + 1 < cnt && (buf[idx + 1] & sym_mask) == km);
+      sl = SLACK && E.v.a + ((u32)me & E.v.posmask) >= E.leaf_end;
+    }
+    const u64 tm = __ballot(tied);
+    tied_bits |= (u32)tied << r;
+    if (lane == 0) tied_mask[r * BK_WAVES + w] = tm;
+    if (SLACK) {
+      const u64 sm = __ballot(sl);
+      slack_bits |= (u32)sl << r;
+      if (lane == 0) slack_mask[r * BK_WAVES + w] = sm;
+    }
+  }
+  lds_barrier();
+  {
+    const u32 tc = tid < BK_MASKS ? (u32)__popcll(tied_mask[tid]) : 0u;
+    const u32 sc = (SLACK && tid < BK_MASKS) ? (u32)__popcll(slack_mask[tid]) : 0u;
+    const u32 both = tc | (sc << 16);  // either total is at most BK_CAP
+    u32 incl = wave_scan_incl_sum(both);
+    if (lane == 63 && w < 4) scan_s[w] = incl;
+    lds_barrier();
+    for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
+    if (tid < BK_MASKS) {
+      tied_pre[tid] = (incl - both) & 0xFFFFu;
+      if (SLACK) slack_pre[tid] = (incl - both) >> 16;
+    }
+    if (tid == BK_MASKS - 1) tied_pre[BK_MASKS] = incl & 0xFFFFu;
+  }
+  lds_barrier();
+  const u32 below = SLACK ? slack_before[blockIdx.x] : 0u;
+#pragma unroll
+  for (int r = 0; r < BK_ITEMS; r++) {
+    const u32 idx = r * BK_THREADS + tid;
+    if (idx < cnt && !((tied_bits >> r) & 1) && !((slack_bits >> r) & 1)) {
+      const u64 me = buf[idx];
+      u32 sb = below;
+      if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
+      E.place((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask), ((u32)me >> E.v.pbits) & 0xFFu);
+    }
+  }
+  const u32 all_tied = tied_pre[BK_MASKS];
+  const BucketWindow win{E.v, buf, (u64)s, cnt};
+  for (u32 t = tid; t < all_tied; t += BK_THREADS) {
+    u32 lo = 0, hi = BK_MASKS;  // the last flag word whose prefix is <= t
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) / 2;
+      if (tied_pre[mid] <= t) lo = mid;
+      else hi = mid;
+    }
+    // flag word lo = r * 16 + w covers the indices r * 1024 + w * 64 + lane
+    const u32 idx = lo * 64 + select_bit(tied_mask[lo], t - tied_pre[lo]);
+    u32 sb = below;
+    if (SLACK) sb += slack_pre[idx >> 6] + (u32)__popcll(slack_mask[idx >> 6] & ((1ull << (idx & 63)) - 1ull));
+    E.direct_tied(win, (u64)s + idx, sb);
+  }
+}
+
+// key of window position a + i as the first radix pass builds it (TextKeys); one position per thread:
+// counts the window-slack positions per bucket
+__global__ void k_slack_buckets(TextKeys tk, u64 first, u64 count, u32 *__restrict__ per_bucket) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const u64 p = first + t;
+  const u32 ms = tk.min_sym - (u32)tk.one_based;
+  u64 sf = 0;
+  for (int k = 0; k < tk.K0; k++) {
+    const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
+    sf = (sf << tk.w) | (ch ? ch - ms : 0u);
+  }
+  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> 48)], 1u);
+}
+
 template <class View>
 struct LeafFilterIn {
   View v;
@@ -708,7 +883,8 @@ static KeyPlan plan_keys(int span, int raw_bits, u64 N) {  // span = max_sym - m
 // the first active list; grp_buf: N more words (pairs: the unused value buffer).
 template <class View>
 static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_mask, View v, u32 *sa_w, u64 *e_w,
-                          u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out) {
+                          u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out, BucketState *bs = nullptr,
+                          const TextKeys *tk = nullptr) {
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
@@ -736,7 +912,30 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     em.T = c.T;
     em.n = (u64)c.n;
     const u32 tiles = (u32)ceil_div(N, DE_TILE);
-    if (e == b) {
+    bool from_buckets = false;
+    if constexpr (std::is_same_v<View, PackedView>) {
+      if (bs && bs->pending) {
+        from_buckets = true;
+        KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
+        if (e == b) {
+          hipLaunchKernelGGL((k_bucket_emit<false>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
+                             (const u32 *)bs->start.get(), (const u32 *)nullptr, bs->begin_bit);
+          HIP_CHECK(hipGetLastError());
+        } else {
+          DBuf<u32> sb(c, BK_BUCKETS);
+          HIP_CHECK(hipMemsetAsync(sb.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
+          hipLaunchKernelGGL(k_slack_buckets, dim3(ceil_div((u64)(e - b), 256)), dim3(256), 0, c.stream, *tk, (u64)b,
+                             (u64)(e - b), sb.get());
+          HIP_CHECK(hipGetLastError());
+          scan_generic<u32, SumU32>(c, BK_BUCKETS, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, BK_BUCKETS});
+          hipLaunchKernelGGL((k_bucket_emit<true>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
+                             (const u32 *)bs->start.get(), (const u32 *)sb.get(), bs->begin_bit);
+          HIP_CHECK(hipGetLastError());
+        }
+      }
+    }
+    if (from_buckets) {
+    } else if (e == b) {
       hipLaunchKernelGGL((k_direct_emit<View, false>), dim3(tiles), dim3(DE_THREADS), 0, c.stream, em,
                          (const u32 *)nullptr);
       HIP_CHECK(hipGetLastError());
@@ -752,6 +951,10 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     if (read_u32(c, d_fail) == 0) {
       if (sa_out) *sa_out = std::move(res);
       return true;
+    }
+    if (from_buckets) {  // the general path wants the whole window sorted in memory
+      bucket_sort_in_place(c, e_w, N, *bs);
+      bs->pending = false;
     }
   }
   u32 *wl_slot = scratch;
@@ -863,15 +1066,16 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
     // packed elements; the spare buffer later holds the first active list (2N words)
     DBuf<u64> eb0(c, N), eb1(c, N);
     DBuf<u32> grp(c, N);
+    BucketState bs;
     u64 *el[2] = {eb0.get(), eb1.get()};
     int cur;
     {
       Phase ph(c, "leaf_radix_sort", (double)N * (passes * 24 - 15));
-      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk);
+      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, &bs);
     }
     PackedView v{el[cur], nullptr, (u32)a, (u32)((1ull << kp.pbits) - 1), kp.pbits};
     return finish_window<PackedView>(c, a, b, e, N, K0, sym_mask, v, nullptr, el[cur], (u32 *)el[cur ^ 1], grp.get(), E,
-                                     sa_out);
+                                     sa_out, &bs, &tk);
   }
   const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
   DBuf<u64> kb0(c, stride), kb1(c, stride);
