@@ -5,37 +5,60 @@ import os
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec sheet); a plain copy kernel reaches about 6300 GB/s
 SECTOR = 64            # bytes the memory side moves for one random rank-block read
 
-# the leaf sort's scatter pass, in whichever layout the run used: (timer, kernel, algorithmic bytes per suffix)
-DOMINANT = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<u64,keys> (packed 8-byte elements)", 16),
-            ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<u64,pairs,split>", 24)]
+# Kernels that can dominate a build: (timer, kernel, what the timer's `work` counts, algorithmic unit).
+#   bytes:   `work` is algorithmic bytes summed over launches
+#   sectors: `work` is random 64-byte reads summed over launches (one rank block per wavelet level and LF step,
+#            one text sector every 16th step); achieved bytes = sectors * 64
+CANDIDATES = [
+    ("gap_chains", "k_chains (LF-mapping chains of the gap array)", "sectors",
+     "read: 64 B per wavelet level and right-block position (one rank block) + 4 B every 16th position (text); written, not counted in `achieved`: 4 B per position"),
+    ("leaf:k_bucket_emit", "k_bucket_emit (rank a bucket in LDS, order ties by text comparison, emit the leaf)", "bytes",
+     "8 B per window suffix read + 1 B per leaf suffix written"),
+    ("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<u64,keys> (packed 8-byte elements)", "bytes", "16 B per window suffix"),
+    ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<u64,pairs,split>", "bytes", "24 B per window suffix"),
+    ("leaf:k_rs_scatter_text", "k_rs_scatter<text> (first pass: keys rolled from the text)", "bytes",
+     "1 B read + 8 or 12 B written per window suffix"),
+]
 
 # what a timer's `work` counts, for timers that do not count bytes
 TRANSACTION_TIMERS = {"gap_chains": "64-byte random reads (one rank block per wavelet level and LF step, text every 16th step)"}
 
 
+def _rate(timers, name, kind):
+    ms, work, calls = timers[name]
+    return work * (SECTOR if kind == "sectors" else 1) / (ms * 1e-3) / 1e9
+
+
 def roofline(timers, repo_root=None, workload=None):
-    """HBM roofline of the dominant kernel: the leaf sort's scatter pass, which reads and writes every element
-    once (16 algorithmic bytes per suffix with packed elements, 24 with key + position pairs).  `work` of its
-    timer is bytes summed over launches."""
-    found = [d for d in DOMINANT if d[0] in timers and timers[d[0]][2] > 0]
+    """HBM roofline of the dominant kernel = the candidate with the largest total time in this run.  Every candidate
+    is bound by HBM: streaming bytes for the sort and emit kernels, random 64-byte sectors for the LF chains.
+    `others` lists the remaining candidates' rates."""
+    found = [d for d in CANDIDATES if d[0] in timers and timers[d[0]][2] > 0 and timers[d[0]][0] > 0]
     if not found:
         return None
-    name, kernel, per_suffix = max(found, key=lambda d: timers[d[0]][0])
+    found.sort(key=lambda d: -timers[d[0]][0])
+    name, kernel, kind, unit = found[0]
     ms, work, calls = timers[name]
-    achieved = work / (ms * 1e-3) / 1e9
+    achieved = _rate(timers, name, kind)
+    per_launch = work * (SECTOR if kind == "sectors" else 1) / calls
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-            "algorithmic_bytes_per_suffix": per_suffix,
-            "bytes_per_launch": work / calls, "avg_launch_ms": round(ms / calls, 4), "launches": calls}
+            "access": "random 64-byte sectors" if kind == "sectors" else "streaming",
+            "algorithmic_unit": unit, "bytes_per_launch": per_launch, "avg_launch_ms": round(ms / calls, 4),
+            "launches": calls, "share_of_timed_kernels": None}
     # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
-    # runs, corrected as the gfx950 notes prescribe); only valid for the workload they were taken on
+    # runs, corrected per kernel as the file says); only valid for the workload they were taken on
     if repo_root and workload:
-        tfile = os.path.join(repo_root, "profiles", "r1_traffic_rs_scatter.json")
+        tfile = os.path.join(repo_root, "profiles", "r1_traffic.json")
         if os.path.exists(tfile):
             t = json.load(open(tfile))
-            if t.get("workload") == workload and t.get("timer", "leaf:k_rs_scatter_u64_pairs") == name:
-                roof["traffic"] = t["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_traffic_rs_scatter.json"
+            if t.get("workload") == workload and name in t.get("kernels", {}):
+                roof["traffic"] = t["kernels"][name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r1_traffic.json"
+    roof["others"] = [{"kernel": d[1], "ms_total": round(timers[d[0]][0], 3), "launches": timers[d[0]][2],
+                       "achieved": round(_rate(timers, d[0], d[2]), 1),
+                       "frac": round(_rate(timers, d[0], d[2]) / HBM_PEAK_GBS, 4)} for d in found[1:]]
+    del roof["share_of_timed_kernels"]
     return roof
 
 

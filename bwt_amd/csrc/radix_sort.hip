@@ -597,6 +597,55 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_sort(u64 *__restrict__ e,
   for (u32 i = tid; i < cnt; i += BK_THREADS) mine[i] = buf[i];
 }
 
+// per_bucket[k] += the sampled text positions whose key, as the first radix pass builds it (TextKeys), has top
+// 16 bits k.  Samples: `count` positions from `first` on, in runs of 16 consecutive positions that start
+// `stride` apart (stride 16: every position).  One position per thread.
+__global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride, u32 *__restrict__ per_bucket) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const u64 p = first + (t >> 4) * stride + (t & 15);
+  const u32 ms = tk.min_sym - (u32)tk.one_based;
+  u64 sf = 0;
+  for (int k = 0; k < tk.K0; k++) {
+    const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
+    sf = (sf << tk.w) | (ch ? ch - ms : 0u);
+  }
+  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> 48)], 1u);
+}
+
+void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_bucket_histogram, dim3(ceil_div(count, 256)), dim3(256), 0, c.stream, tk, first, count, stride,
+                     per_bucket);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ void k_max_u32(const u32 *__restrict__ v, u32 n, u32 *__restrict__ out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 x = wave_reduce_max(k < n ? v[k] : 0u);
+  if (lane_id() == 0) atomicMax(out, x);
+}
+
+// A sample of the window (16 positions out of every 4096) says whether some bucket will be far too large
+// for a workgroup (twice its capacity: sampling noise must not turn an even text away); the two passes on
+// the top 16 bits are then not worth trying.
+static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n) {
+  constexpr u64 STRIDE = 256;  // one position in 256
+  const u64 count = n / (16 * STRIDE) * 16;
+  if (count < 4 * BK_BUCKETS) return true;  // too few samples to say anything
+  KernelTimer kt(c, "leaf:k_bucket_histogram", (double)count * 8);
+  DBuf<u32> hist(c, BK_BUCKETS);
+  u32 *d_max = c.d_scalars + 12;
+  HIP_CHECK(hipMemsetAsync(hist.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
+  HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
+  bucket_histogram(c, tk, tk.a, count, 16 * STRIDE, hist.get());
+  hipLaunchKernelGGL(k_max_u32, dim3(BK_BUCKETS / 256), dim3(256), 0, c.stream, hist.get(), BK_BUCKETS, d_max);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  return (u64)c.h_scalars[0] * STRIDE <= (u64)BK_CAP * 2;
+}
+
 // Bucket bounds of e (already sorted on its top 16 bits).  False if some bucket does not fit a workgroup.
 static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start) {
   start = DBuf<u32>(c, BK_BUCKETS + 1);
@@ -630,7 +679,7 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
   if (begin_bit % 8 != 0 || begin_bit < 32 || begin_bit >= 64 || text.pbits <= 0 || text.pbits > 31 ||
       (n - 1) >> text.pbits)
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad packed layout (begin_bit %d, pbits %d, n %zu)", begin_bit, text.pbits, n);
-  if (begin_bit < 48 && n >= c.bucket_min_n) {
+  if (begin_bit < 48 && n >= c.bucket_min_n && buckets_look_even(c, text, n)) {
     // top 16 bits by two passes (the first one reverse-stable from the text, as always), the rest per bucket
     const int cur = leaf_sort_text_packed(c, elems, n, 48, text, nullptr);
     BucketState local;

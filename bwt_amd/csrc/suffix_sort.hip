@@ -766,21 +766,6 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   }
 }
 
-// key of window position a + i as the first radix pass builds it (TextKeys); one position per thread:
-// counts the window-slack positions per bucket
-__global__ void k_slack_buckets(TextKeys tk, u64 first, u64 count, u32 *__restrict__ per_bucket) {
-  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= count) return;
-  const u64 p = first + t;
-  const u32 ms = tk.min_sym - (u32)tk.one_based;
-  u64 sf = 0;
-  for (int k = 0; k < tk.K0; k++) {
-    const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
-    sf = (sf << tk.w) | (ch ? ch - ms : 0u);
-  }
-  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> 48)], 1u);
-}
-
 template <class View>
 struct LeafFilterIn {
   View v;
@@ -924,9 +909,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
         } else {
           DBuf<u32> sb(c, BK_BUCKETS);
           HIP_CHECK(hipMemsetAsync(sb.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
-          hipLaunchKernelGGL(k_slack_buckets, dim3(ceil_div((u64)(e - b), 256)), dim3(256), 0, c.stream, *tk, (u64)b,
-                             (u64)(e - b), sb.get());
-          HIP_CHECK(hipGetLastError());
+          bucket_histogram(c, *tk, (u64)b, (u64)(e - b), 16, sb.get());
           scan_generic<u32, SumU32>(c, BK_BUCKETS, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, BK_BUCKETS});
           hipLaunchKernelGGL((k_bucket_emit<true>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
                              (const u32 *)bs->start.get(), (const u32 *)sb.get(), bs->begin_bit);

@@ -60,6 +60,19 @@ def main():
     ctx.reset_timers()
     same_as_oracle(ctx, T, 4, 70000, 1000)
     assert launches(ctx, "leaf:k_bucket_emit") > 0 and launches(ctx, "leaf:k_bucket_sort") > 0
+    # a long skewed text: a sample of the window already says that the buckets will not fit
+    n = 70000000
+    T = np.concatenate([np.where(rng.random(n) < 0.9, 1, rng.integers(1, 5, n)).astype(np.uint8),
+                        np.zeros(1, dtype=np.uint8)])
+    ctx.set_text(T)
+    ctx.reset_timers()
+    blk = ctx.pmbwt(len(T), 4000)
+    assert launches(ctx, "leaf:k_bucket_histogram") > 0 and launches(ctx, "leaf:k_bucket_bounds") == 0
+    L = blk.L
+    assert (np.bincount(L, minlength=5) == np.bincount(T, minlength=5)).all()
+    r, p = blk.samples()
+    assert (L[r] == T[p - 1]).all()
+    del T, L
     # 4e6 suffixes: 16 symbols per key, two ranking rounds per bucket; against the four plain passes
     n = 4000000
     ctx.gen_text(n, 9, 4)

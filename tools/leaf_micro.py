@@ -14,10 +14,12 @@ for a, b in [(0, n // 2), (n // 2, n)]:
     for rep in range(2):
         ctx.set_timing(2)
         ctx.reset_timers()
-        blk = ctx.leaf(a, b, 10000)
+        try:
+            ctx.leaf(a, b, 10000).free()
+        except bwt_amd.BwtHipError as e:  # an instrumented build may leave the leaf incomplete: the times still count
+            print("  (%s)" % e)
         t = ctx.timers()
         ctx.set_timing(0)
-        blk.free()
     print("leaf [%d, %d)" % (a, b))
     for name, (ms, work, calls) in sorted(t.items(), key=lambda kv: -kv[1][0]):
         print("  %-30s %8.3f ms  (%d launches)  %.0f GB/s" % (name, ms, calls, work / (ms * 1e-3) / 1e9 if ms else 0))

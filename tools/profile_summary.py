@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses the output of tools/profile_round.sh into the files kept under profiles/:
-   <tag>_kernel_stats.csv, <tag>_pmc_traffic_n1e9.txt, <tag>_traffic_rs_scatter.json, <tag>_bench_under_rocprof.json"""
+   <tag>_kernel_stats.csv, <tag>_pmc_traffic_n1e9.txt, <tag>_traffic.json, <tag>_bench_under_rocprof.json"""
 import csv
 import glob
 import json
@@ -41,21 +41,28 @@ def main():
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
         lines.append("%-100s %6d %14.1f %14.1f" % (k[:100], fetch[k][1], fetch[k][0] / 1e3, write.get(k, (0, 0))[0] / 1e3))
     open(os.path.join(dst, tag + "_pmc_traffic_n1e9.txt"), "w").write("\n".join(lines) + "\n")
-    # the leaf sort's scatter pass: packed elements (keys only) or key + position pairs, whichever the run used
-    cands = [(k, "leaf:k_rs_scatter_u64_keys") for k in fetch if "k_rs_scatter<unsigned long, false, 0, false, false>" in k]
-    cands += [(k, "leaf:k_rs_scatter_u64_pairs") for k in fetch if "k_rs_scatter<unsigned long, true, 0, false, true>" in k]
-    name, timer = cands[0]
-    f_kb, n_launch = fetch[name]
-    w_kb = write[name][0]
+    # per timer of bench.py's roofline candidates: the kernel's traffic per launch.  Streaming kernels: FETCH_SIZE x2
+    # (gfx950 counts a 128-byte request of a coalesced streaming read as 64 bytes).  k_chains reads random 64-byte
+    # sectors, which the counter reports as they are (checked against the known count: one sector per LF step).
+    pats = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<unsigned long, false, 0, false, false>", 2),
+            ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<unsigned long, true, 0, false, true>", 2),
+            ("gap_chains", "k_chains<", 1)]
+    kernels = {}
+    for timer, pat, mult in pats:
+        for k in fetch:
+            if pat in k:
+                f_kb, n_launch = fetch[k]
+                w_kb = write.get(k, (0, 0))[0]
+                kernels[timer] = {"kernel": k.split("(")[0], "launches": n_launch, "FETCH_SIZE_KB_per_launch": f_kb,
+                                  "WRITE_SIZE_KB_per_launch": w_kb,
+                                  "correction": "FETCH_SIZE x%d; WRITE_SIZE as is" % mult,
+                                  "hbm_bytes_per_launch": (mult * f_kb + w_kb) * 1024}
+                break
     json.dump({
         "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --steps 1 --warmup 0 --cpu_n 0 --no-timers",
-        "workload": {"n": 1000000000, "leaves": 2}, "timer": timer,
-        "kernel": name.split("(")[0], "launches": n_launch,
-        "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
-        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of coalesced streaming reads as 64 B); WRITE_SIZE as is",
-        "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
-    }, open(os.path.join(dst, tag + "_traffic_rs_scatter.json"), "w"), indent=1)
-    print(open(os.path.join(dst, tag + "_traffic_rs_scatter.json")).read())
+        "workload": {"n": 1000000000, "leaves": 2}, "kernels": kernels,
+    }, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+    print(open(os.path.join(dst, tag + "_traffic.json")).read())
     print("\n".join(lines[:14]))
 
 
