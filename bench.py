@@ -23,6 +23,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: the reference prints its own timing line with printf, and
+    this program's standard output is one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # the C library's buffer, before descriptor 1 comes back
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cpu_baseline(budget_n):
     """The reference itself (oracle/_ref, serial build) or, without it, the C oracle, on a bounded sample."""
     import numpy as np  # noqa: F401
@@ -31,7 +47,8 @@ def cpu_baseline(budget_n):
     T = gen_text(n, 42, 4)
     t0 = time.perf_counter()
     if Reference.available():
-        blk = Reference.pmbwt(T, alpha_min=1, alpha_max=4)
+        with stdout_to_stderr():
+            blk = Reference.pmbwt(T, alpha_min=1, alpha_max=4)
         kind = "reference"
         what = "taura/bwt pmbwt, serial build (parallel_model_none: TBB headers absent), -O3 -DNDEBUG"
     else:
