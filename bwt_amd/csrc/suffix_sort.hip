@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
 
 // ----------------------------------------------------------------------------
 // Bucket route (packed layout): the radix passes have stopped after the top 16 key bits.  One workgroup
-// loads a bucket, ranks it on the remaining key bits in LDS (bk_rank) and, instead of writing the sorted
+// loads a bucket, orders it on the remaining key bits in LDS and, instead of writing the sorted
 // bucket back for k_direct_emit to read it again, does that kernel's work straight from LDS: unique keys
 // are emitted where they stand, tied ones by LeafEmit::direct_tied.  Groups of equal keys never straddle
 // buckets.  slack_before[k] = window-slack positions in the buckets below k.
@@ -668,37 +668,77 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   const u32 wbase = w * BK_PER_WAVE;
   const u64 *mine = E.v.e + s;
   {
-    u32(*ctr)[256] = reinterpret_cast<u32(*)[256]>(buf);
+    // Order of the bucket by the 16 key bits below the bucket's own (zero padding included when the key is
+    // shorter).  No order is needed among equal keys -- ties are decided on the text -- so one counting round
+    // does: a 4-bit counter per key value (65536 of them, 8 per word; they use the buffer while the elements
+    // are in registers), one atomic add per element whose old value numbers the element among its equals,
+    // prefix sums of the counters per word, rank = keys below + own number.  A value that occurs more than
+    // 15 times gives the direct pass up (the general path can order large groups).
+    constexpr u32 NIB_WORDS = 8192;
+    static_assert(NIB_WORDS == 8 * BK_THREADS && NIB_WORDS * 4 + NIB_WORDS * 2 <= sizeof(u64) * BK_CAP, "counters fit the buffer");
+    u32 *nib = reinterpret_cast<u32 *>(buf);
+    u16 *wpre = reinterpret_cast<u16 *>(nib + NIB_WORDS);  // counters in the words below word j
     u64 key[BK_ITEMS];
-    u32 pos[BK_ITEMS];
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
       const u32 idx = wbase + r * 64 + lane;
       key[r] = idx < cnt ? mine[idx] : 0ull;
-      pos[r] = idx;
     }
-#pragma unroll 1
-    for (int shift = begin_bit; shift < 48; shift += 8) {
-      bk_rank(key, shift, cnt, ctr, scan_s, pos);
+    reinterpret_cast<uint4 *>(nib)[tid * 2] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4 *>(nib)[tid * 2 + 1] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) scan_s[3] = 0;
+    lds_barrier();
+    u64 ord = 0;  // 4 bits per element: its number among the elements of the same key
+    bool full = false;
 #pragma unroll
-      for (int r = 0; r < BK_ITEMS; r++)
-        if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
-      lds_barrier();
-      if (shift + 8 < 48) {
-#pragma unroll
-        for (int r = 0; r < BK_ITEMS; r++) {
-          const u32 idx = wbase + r * 64 + lane;
-          key[r] = idx < cnt ? buf[idx] : 0ull;
-        }
-        lds_barrier();  // the next round's counters overwrite the buffer
+    for (int r = 0; r < BK_ITEMS; r++) {
+      if (wbase + r * 64 + lane < cnt) {
+        const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
+        const u32 old = (atomicAdd(&nib[k >> 3], 1u << sh) >> sh) & 15u;
+        full = full || old == 15u;
+        ord |= (u64)old << (4 * r);
       }
     }
-    if (begin_bit >= 48) {  // nothing left to sort on
-#pragma unroll
-      for (int r = 0; r < BK_ITEMS; r++)
-        if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
-      lds_barrier();
+    if (full) scan_s[3] = 1;
+    lds_barrier();
+    if (scan_s[3]) {  // the same for every thread
+      if (tid == 0) *E.fail = 1;
+      return;
     }
+    {
+      const uint4 x0 = reinterpret_cast<const uint4 *>(nib)[tid * 2], x1 = reinterpret_cast<const uint4 *>(nib)[tid * 2 + 1];
+      const u32 xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      u32 run[8], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        run[j] = sum;
+        const u32 y = (xs[j] & 0x0F0F0F0Fu) + ((xs[j] >> 4) & 0x0F0F0F0Fu);
+        sum += (y * 0x01010101u) >> 24;
+      }
+      u32 incl = wave_scan_incl_sum(sum);
+      __shared__ u32 wave_sum[BK_WAVES];
+      if (lane == 63) wave_sum[w] = incl;
+      lds_barrier();
+      u32 base = incl - sum;
+      for (u32 k = 0; k < w; k++) base += wave_sum[k];
+      reinterpret_cast<uint4 *>(wpre)[tid] =
+          make_uint4((base + run[0]) | ((base + run[1]) << 16), (base + run[2]) | ((base + run[3]) << 16),
+                     (base + run[4]) | ((base + run[5]) << 16), (base + run[6]) | ((base + run[7]) << 16));
+    }
+    lds_barrier();
+    u32 pos[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {
+      const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
+      const u32 below = nib[k >> 3] & ((1u << sh) - 1u);
+      const u32 y = (below & 0x0F0F0F0Fu) + ((below >> 4) & 0x0F0F0F0Fu);
+      pos[r] = wpre[k >> 3] + ((y * 0x01010101u) >> 24) + ((u32)(ord >> (4 * r)) & 15u);
+    }
+    lds_barrier();  // the counters are dead: the buffer takes the elements
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++)
+      if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
+    lds_barrier();
   }
   // flags: thread t looks at the sorted indices r * 1024 + t, so flag word r * 16 + w covers 64 consecutive ones
   const u64 sym_mask = E.sym_mask;  // its low word is zero: raw elements compare like keys
