@@ -340,8 +340,9 @@ struct LeafEmit : EmitParams {
 
   // special ranks and samples of the suffix at `pos`, which has leaf rank r
   __device__ __forceinline__ void note(u64 r, u32 pos) const {
-    if (pos == a) special[0] = (u32)r;          // s_rank
-    if (pos + 1 == a + m) special[1] = (u32)r;  // e_rank
+    const u32 rel32 = pos - (u32)a;                // all positions are below 2^32
+    if (rel32 == 0) special[0] = (u32)r;           // s_rank
+    if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
     if (m == 1) {
       samp_rank[0] = (u32)r;
       samp_pos[0] = pos;
@@ -354,10 +355,9 @@ struct LeafEmit : EmitParams {
     // slow and most positions are not sampled: position i is sampled iff the fractional part of
     // i*(ns-1)/(m-1) is below (ns-1)/(m-1), so one multiplication (error far below the 2^-16
     // margin for any ns < 2^36) rules out the rest.
-    i64 rel = (i64)(pos - a);
-    if (rel != 0) {
-      double t = (double)rel * samp_ratio;
-      double f = t - floor(t);
+    const i64 rel = (i64)rel32;
+    if (rel32 != 0) {
+      const double f = __builtin_amdgcn_fract((double)rel32 * samp_ratio);
       if (f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16) return;
     }
     i64 A = ns - 1;
@@ -741,17 +741,17 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     lds_barrier();
   }
   // flags: thread t looks at the sorted indices r * 1024 + t, so flag word r * 16 + w covers 64 consecutive ones
-  const u64 sym_mask = E.sym_mask;  // its low word is zero: raw elements compare like keys
+  const u32 mask_hi = (u32)(E.sym_mask >> 32);  // the symbol codes are the high word of an element
+  const u32 *hiw = reinterpret_cast<const u32 *>(buf) + 1;  // hiw[2 * i]: high word of element i
   u32 tied_bits = 0, slack_bits = 0;
 #pragma unroll
   for (int r = 0; r < BK_ITEMS; r++) {
     const u32 idx = r * BK_THREADS + tid;
     bool tied = false, sl = false;
     if (idx < cnt) {
-      const u64 me = buf[idx];
-      const u64 km = me & sym_mask;
-      tied = (idx > 0 && (buf[idx - 1] & sym_mask) == km) || (idx + 1 < cnt && (buf[idx + 1] & sym_mask) == km);
-      sl = SLACK && E.v.a + ((u32)me & E.v.posmask) >= E.leaf_end;
+      const u32 km = hiw[2 * idx] & mask_hi;
+      tied = (idx > 0 && (hiw[2 * idx - 2] & mask_hi) == km) || (idx + 1 < cnt && (hiw[2 * idx + 2] & mask_hi) == km);
+      sl = SLACK && E.v.a + (hiw[2 * idx - 1] & E.v.posmask) >= E.leaf_end;
     }
     const u64 tm = __ballot(tied);
     tied_bits |= (u32)tied << r;
