@@ -44,8 +44,8 @@ def main():
     # per timer of bench.py's roofline candidates: the kernel's traffic per launch.  Streaming kernels: FETCH_SIZE x2
     # (gfx950 counts a 128-byte request of a coalesced streaming read as 64 bytes).  k_chains reads random 64-byte
     # sectors, which the counter reports as they are (checked against the known count: one sector per LF step).
-    pats = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<unsigned long, false, 0, false, false>", 2),
-            ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<unsigned long, true, 0, false, true>", 2),
+    pats = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<unsigned long, false, 0, false, false,", 2),
+            ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<unsigned long, true, 0, false, true,", 2),
             ("gap_chains", "k_chains<", 1)]
     kernels = {}
     for timer, pat, mult in pats:
