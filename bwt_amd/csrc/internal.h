@@ -210,11 +210,12 @@ int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 // a partial BWT resident on the device (include/bwt.h:122-149 of the reference)
 // ---------------------------------------------------------------------------
 struct WaveletDev {
-  int levels = 0;        // two code bits per level
+  int levels = 0;
+  int dbits = 2;         // code bits per level: 2 (alphabets of up to four symbols) or 4
   u32 min_sym = 1;       // code = symbol - min_sym
   u64 n_blk = 0;         // rank blocks per level
-  DBuf<u64> planes;      // levels * n_blk * 16 words
-  u32 start[4][4] = {};  // per level: first position of each digit's bucket on the next level
+  DBuf<u64> planes;      // levels * n_blk * (8 or 16) words
+  u32 start[4][16] = {}; // per level: first position of each digit's bucket on the next level
   DBuf<u32> lf_base;     // 512 entries: C[c] - p_end[c], then p_end[c]
   bool built = false;
 };

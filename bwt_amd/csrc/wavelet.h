@@ -36,14 +36,22 @@ constexpr u32 WM_BLOCK_POS = 64 * WM_CHUNKS;       // positions per rank block
 constexpr u32 WM_BLOCK_WORDS = 2 + 2 * WM_CHUNKS;  // 64-bit words per rank block (64 bytes)
 constexpr int WM_MAX_LEVELS = 4;
 
+// Alphabets of more than four symbols take four code bits per level instead of two (16-ary levels): a rank
+// block is then 128 bytes = 16 x u32 digit counts + four bit planes of 128 positions (plane b: one word for
+// positions 0..63, one for 64..127).  The memory side serves a random 128-byte line at the same rate as a
+// random 64-byte sector, so a byte alphabet costs two requests per LF step instead of four.
+constexpr u32 WM16_BLOCK_POS = 128;
+constexpr u32 WM16_BLOCK_WORDS = 16;
+
 struct WmView {
   const u64 *planes;
   u64 level_words;
   int levels;
+  int dbits;                 // code bits per level: 2 (64-byte blocks) or 4 (128-byte blocks)
   u32 min_sym;
   u32 max_pos;               // last position that has a rank block (>= the block length)
   u32 hidden;                // position of the foreign symbol
-  u32 start[WM_MAX_LEVELS][4];  // first position of each digit's bucket on the NEXT level
+  u32 start[WM_MAX_LEVELS][16];  // first position of each digit's bucket on the NEXT level
 };
 
 // occurrences of digit d in level[0:pos)
@@ -68,9 +76,37 @@ __device__ __forceinline__ u32 wm_rank_digit(const u64 *__restrict__ lvl, u32 po
   return cnt;
 }
 
+// occurrences of the 4-bit digit d in level[0:pos), 16-ary levels
+__device__ __forceinline__ u32 wm_rank_digit16(const u64 *__restrict__ lvl, u32 pos, u32 d) {
+  const u32 blk = pos / WM16_BLOCK_POS, off = pos % WM16_BLOCK_POS;
+  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM16_BLOCK_WORDS);
+  const uint4 h = p[d >> 2];  // the four counts that hold d's
+  uint4 pl[4];
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) pl[b] = p[4 + b];
+  u32 cnt = (d & 3) == 0 ? h.x : ((d & 3) == 1 ? h.y : ((d & 3) == 2 ? h.z : h.w));
+  u64 m0 = ~0ull, m1 = ~0ull;  // positions 0..63 and 64..127 that hold digit d
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) {
+    const u64 inv = ((d >> b) & 1) ? 0ull : ~0ull;
+    m0 &= (((u64)pl[b].y << 32) | pl[b].x) ^ inv;
+    m1 &= (((u64)pl[b].w << 32) | pl[b].z) ^ inv;
+  }
+  const u64 k0 = off >= 64 ? ~0ull : ((1ull << off) - 1), k1 = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+  return cnt + __popcll(m0 & k0) + __popcll(m1 & k1);
+}
+
 // position reached by walking index i down all levels along the digits of code
 __device__ __forceinline__ u32 wm_walk(const WmView &wm, u32 code, u32 i) {
   u32 q = i;
+  if (wm.dbits == 4) {
+    for (int l = 0; l < wm.levels; l++) {
+      q = q < wm.max_pos ? q : wm.max_pos;
+      const u32 d = (code >> (4 * (wm.levels - 1 - l))) & 15;
+      q = wm.start[l][d] + wm_rank_digit16(wm.planes + (u64)l * wm.level_words, q, d);
+    }
+    return q;
+  }
   for (int l = 0; l < wm.levels; l++) {
     q = q < wm.max_pos ? q : wm.max_pos;  // never read past the planes, whatever the caller passes
     u32 d = (code >> (2 * (wm.levels - 1 - l))) & 3;

@@ -313,6 +313,113 @@ __global__ void k_wm_starts(const u32 *__restrict__ tile_off, u32 tiles, u32 *__
   if (threadIdx.x < 4) starts[threadIdx.x] = tile_off[(u64)threadIdx.x * tiles];
 }
 
+// ----------------------------------------------------------------------------
+// 16-ary levels (WM16_*): the same three steps per level with four bit planes
+// ----------------------------------------------------------------------------
+constexpr int WM16_TILE_BLOCKS = WM_TILE / WM16_BLOCK_POS;  // 24 rank blocks of 128 positions
+static_assert(WM_TILE % WM16_BLOCK_POS == 0, "a tile holds whole rank blocks");
+
+// this lane's digit among the wave's 64: the lanes that hold digit `d`, from the four ballots
+__device__ __forceinline__ u64 wm16_select(const u64 (&bal)[4], u32 d) {
+  u64 sel = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 4; b++) sel &= ((d >> b) & 1) ? bal[b] : ~bal[b];
+  return sel;
+}
+
+// the four bit planes of one tile by wave ballots, and the tile's 16 digit counts
+__global__ void __launch_bounds__(WM_THREADS)
+    k_wm_plane16(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u32 min_sym, int raw,
+                 u64 *__restrict__ plane, u32 *__restrict__ tile_cnt, u32 tiles) {
+  __shared__ u32 wc[WM_THREADS / 64][16];
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile0 = blockIdx.x * WM_TILE;
+  u32 mine = 0;  // lane d < 16: occurrences of digit d in this wave's rounds
+#pragma unroll
+  for (int r = 0; r < WM_ROUNDS; r++) {
+    const u32 wi = r * (WM_THREADS / 64) + w;  // 64-position word of the tile
+    const u32 idx = tile0 + wi * 64 + lane;
+    const u32 d = (wm_code(cur, idx, m, hidden, min_sym, raw) >> shift) & 15;
+    const u64 bal[4] = {__ballot(d & 1), __ballot(d & 2), __ballot(d & 4), __ballot(d & 8)};
+    const u64 v = __ballot(idx < m);
+    if (lane < 16) mine += __popcll(wm16_select(bal, lane) & v);
+    if (lane < 4) {
+      // plane `lane` of the block: words 8 + 2 * lane (positions 0..63) and 9 + 2 * lane (64..127)
+      u64 *blk = plane + ((u64)blockIdx.x * WM16_TILE_BLOCKS + wi / 2) * WM16_BLOCK_WORDS;
+      blk[8 + 2 * lane + (wi & 1)] = lane == 0 ? bal[0] : (lane == 1 ? bal[1] : (lane == 2 ? bal[2] : bal[3]));
+    }
+  }
+  if (lane < 16) wc[w][lane] = mine;
+  __syncthreads();
+  if (tid < 16) tile_cnt[(u64)tid * tiles + blockIdx.x] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+}
+
+// rank-block headers of one tile: digit counts before each block = the scanned [digit][tile] entry plus the
+// tile's earlier blocks
+__global__ void __launch_bounds__(64)
+    k_wm_headers16(u64 *__restrict__ plane, const u32 *__restrict__ tile_off, u32 tiles) {
+  const u32 d = threadIdx.x;
+  if (d >= 16) return;
+  // the scanned table counts every smaller digit too: take the digit's own start out again
+  u32 run = tile_off[(u64)d * tiles + blockIdx.x] - tile_off[(u64)d * tiles];
+  for (int b = 0; b < WM16_TILE_BLOCKS; b++) {
+    u64 *blk = plane + ((u64)blockIdx.x * WM16_TILE_BLOCKS + b) * WM16_BLOCK_WORDS;
+    reinterpret_cast<u32 *>(blk)[d] = run;
+    u64 m0 = ~0ull, m1 = ~0ull;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 inv = ((d >> k) & 1) ? 0ull : ~0ull;
+      m0 &= blk[8 + 2 * k] ^ inv;
+      m1 &= blk[9 + 2 * k] ^ inv;
+    }
+    run += __popcll(m0) + __popcll(m1);
+  }
+}
+
+// stable 16-way split of the tile's codes (k_wm_split with four planes)
+__global__ void __launch_bounds__(WM_THREADS)
+    k_wm_split16(const u8 *__restrict__ cur, u32 m, int shift, u32 hidden, u32 min_sym, int raw,
+                 const u32 *__restrict__ tile_off, u32 tiles, u8 *__restrict__ next) {
+  __shared__ u32 wcnt[16][WM_TILE_WORDS];  // per word: count of each digit, then exclusive prefix over words
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile0 = blockIdx.x * WM_TILE;
+  u8 code[WM_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < WM_ROUNDS; r++) {
+    const u32 wi = r * (WM_THREADS / 64) + w;
+    const u32 idx = tile0 + wi * 64 + lane;
+    const u32 cd = wm_code(cur, idx, m, hidden, min_sym, raw);
+    code[r] = (u8)cd;
+    const u32 d = (cd >> shift) & 15;
+    const u64 bal[4] = {__ballot(d & 1), __ballot(d & 2), __ballot(d & 4), __ballot(d & 8)};
+    const u64 v = __ballot(idx < m);
+    if (lane < 16) wcnt[lane][wi] = __popcll(wm16_select(bal, lane) & v);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    u32 run = tile_off[(u64)tid * tiles + blockIdx.x];
+    for (int k = 0; k < WM_TILE_WORDS; k++) {
+      const u32 v = wcnt[tid][k];
+      wcnt[tid][k] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < WM_ROUNDS; r++) {
+    const u32 wi = r * (WM_THREADS / 64) + w;
+    const u32 idx = tile0 + wi * 64 + lane;
+    const u32 d = ((u32)code[r] >> shift) & 15;
+    const u64 bal[4] = {__ballot(d & 1), __ballot(d & 2), __ballot(d & 4), __ballot(d & 8)};
+    const u64 v = __ballot(idx < m);
+    if (idx < m) next[wcnt[d][wi] + __popcll(wm16_select(bal, d) & v & lanemask_lt())] = code[r];
+  }
+}
+
+__global__ void k_wm_starts16(const u32 *__restrict__ tile_off, u32 tiles, u32 *__restrict__ starts) {
+  if (threadIdx.x < 16) starts[threadIdx.x] = tile_off[(u64)threadIdx.x * tiles];
+}
+
 // p_end[c]: where the walk of position 0 ends for symbol c; lf_base[c] = C[c] - p_end[c]
 __global__ void k_wm_tables(WmView wm, u32 n_codes, const u32 *__restrict__ C, u32 *__restrict__ tab) {
   u32 c = threadIdx.x;
@@ -327,13 +434,14 @@ WmView make_view(const Block &blk) {
   WmView v;
   memset(&v, 0, sizeof(v));
   v.planes = wm.planes.get();
-  v.level_words = wm.n_blk * WM_BLOCK_WORDS;
+  v.level_words = wm.n_blk * (wm.dbits == 4 ? WM16_BLOCK_WORDS : WM_BLOCK_WORDS);
   v.levels = wm.levels;
+  v.dbits = wm.dbits;
   v.min_sym = wm.min_sym;
-  v.max_pos = (u32)(wm.n_blk * WM_BLOCK_POS - 1);
+  v.max_pos = (u32)(wm.n_blk * (wm.dbits == 4 ? WM16_BLOCK_POS : WM_BLOCK_POS) - 1);
   v.hidden = (u32)blk.s_rank;
   for (int l = 0; l < WM_MAX_LEVELS; l++)
-    for (int d = 0; d < 4; d++) v.start[l][d] = wm.start[l][d];
+    for (int d = 0; d < 16; d++) v.start[l][d] = wm.start[l][d];
   return v;
 }
 
@@ -345,29 +453,52 @@ void build_wavelet(Ctx &c, Block &blk) {
   const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
   int bits = 1;
   while (((c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0) >> bits) != 0) bits++;
-  const int levels = (bits + 1) / 2;
-  Phase ph(c, "wavelet_build", (double)m * levels * 3.3);
+  // up to four symbols: one 2-bit level of 64-byte blocks; larger alphabets: 4-bit levels of 128-byte blocks
+  const int dbits = bits <= 2 ? 2 : 4;
+  const int levels = (bits + dbits - 1) / dbits;
+  const int fan = 1 << dbits;
+  Phase ph(c, "wavelet_build", (double)m * levels * (dbits == 4 ? 4.0 : 3.3));
   const u32 tiles = (u32)(m / WM_TILE) + 1;
-  const u64 n_blk = (u64)tiles * WM_TILE_BLOCKS;
+  const u64 n_blk = (u64)tiles * (dbits == 4 ? WM16_TILE_BLOCKS : WM_TILE_BLOCKS);
+  const u64 blk_words = dbits == 4 ? WM16_BLOCK_WORDS : WM_BLOCK_WORDS;
   WaveletDev &wm = blk.wm;
   wm.levels = levels;
+  wm.dbits = dbits;
   wm.min_sym = min_sym;
   wm.n_blk = n_blk;
-  wm.planes = DBuf<u64>(c, (size_t)levels * n_blk * WM_BLOCK_WORDS);
+  wm.planes = DBuf<u64>(c, (size_t)levels * n_blk * blk_words);
   DBuf<u8> t0, t1;
   if (levels > 1) {
     t0 = DBuf<u8>(c, m);
     t1 = DBuf<u8>(c, m);
   }
-  DBuf<u32> tz(c, (size_t)4 * tiles);
-  u32 *d_starts = c.d_scalars + 24;  // 4 words per level
+  DBuf<u32> tz(c, (size_t)fan * tiles);
+  DBuf<u32> starts(c, 16 * WM_MAX_LEVELS);
+  u32 *d_starts = starts.get();  // `fan` words per level
   const u8 *cur = blk.L.get();
   u8 *bufs[2] = {t0.get(), t1.get()};
   const u32 hidden = (u32)blk.s_rank;
   for (int l = 0; l < levels; l++) {
-    const int shift = 2 * (levels - 1 - l);
+    const int shift = dbits * (levels - 1 - l);
     const int raw = l == 0;
-    u64 *plane = wm.planes.get() + (u64)l * n_blk * WM_BLOCK_WORDS;
+    u64 *plane = wm.planes.get() + (u64)l * n_blk * blk_words;
+    if (dbits == 4) {
+      hipLaunchKernelGGL(k_wm_plane16, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, min_sym,
+                         raw, plane, tz.get(), tiles);
+      HIP_CHECK(hipGetLastError());
+      scan_exclusive_u32(c, tz.get(), tz.get(), (size_t)16 * tiles, nullptr);
+      hipLaunchKernelGGL(k_wm_starts16, dim3(1), dim3(64), 0, c.stream, tz.get(), tiles, d_starts + 16 * l);
+      hipLaunchKernelGGL(k_wm_headers16, dim3(tiles), dim3(64), 0, c.stream, plane, tz.get(), tiles);
+      HIP_CHECK(hipGetLastError());
+      if (l + 1 < levels) {
+        u8 *nxt = bufs[l & 1];
+        hipLaunchKernelGGL(k_wm_split16, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, min_sym,
+                           raw, tz.get(), tiles, nxt);
+        HIP_CHECK(hipGetLastError());
+        cur = nxt;
+      }
+      continue;
+    }
     hipLaunchKernelGGL(k_wm_plane, dim3(tiles), dim3(WM_THREADS), 0, c.stream, cur, (u32)m, shift, hidden, min_sym, raw,
                        plane, tz.get(), tiles);
     HIP_CHECK(hipGetLastError());
@@ -382,17 +513,17 @@ void build_wavelet(Ctx &c, Block &blk) {
       cur = nxt;
     }
   }
-  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_starts, sizeof(u32) * 4 * levels, hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_starts, sizeof(u32) * fan * levels, hipMemcpyDeviceToHost, c.stream));
   c.sync();
   for (int l = 0; l < levels; l++)
-    for (int d = 0; d < 4; d++) wm.start[l][d] = c.h_scalars[4 * l + d];
+    for (int d = 0; d < fan; d++) wm.start[l][d] = c.h_scalars[fan * l + d];
   // LF tables
   u32 hC[256];
   for (int k = 0; k < 256; k++) hC[k] = (u32)blk.C[k];
   DBuf<u32> dC(c, 256);
   HIP_CHECK(hipMemcpyAsync(dC.get(), hC, sizeof(hC), hipMemcpyHostToDevice, c.stream));
   wm.lf_base = DBuf<u32>(c, 512);
-  hipLaunchKernelGGL(k_wm_tables, dim3(1), dim3(256), 0, c.stream, make_view(blk), 1u << (2 * levels), dC.get(),
+  hipLaunchKernelGGL(k_wm_tables, dim3(1), dim3(256), 0, c.stream, make_view(blk), 1u << (dbits * levels), dC.get(),
                      wm.lf_base.get());
   HIP_CHECK(hipGetLastError());
   c.sync();  // hC is on the stack
