@@ -88,9 +88,10 @@ def test_leaf_window_overflow_retry(ctx):
     assert (ctx.leaf_sa(a, b) == Oracle.sa_range(T, a, b)).all()
 
 
-@pytest.mark.parametrize("sigma", [4, 200])
+@pytest.mark.parametrize("sigma", [4, 7, 16, 17, 200])
 def test_rank_and_LF_against_oracle(ctx, sigma):
-    """src/test/test_wavelet_matrix.cc re-expressed: rank(c,p) for random (c,p); LF_map_mod for every rank."""
+    """src/test/test_wavelet_matrix.cc re-expressed: rank(c,p) for random (c,p); LF_map_mod for every rank.
+    The alphabets cover one 2-bit level, one and two 4-bit levels; the positions include rank-block and tile edges."""
     n = 30000
     T = make_text({"kind": "splitmix", "n": n, "seed": 55, "sigma": sigma})
     a, b = 1000, 26000
@@ -105,6 +106,8 @@ def test_rank_and_LF_against_oracle(ctx, sigma):
     syms = rng.randint(1, sigma + 1, size=2000).astype(np.uint8)
     pos = rng.randint(0, b - a + 1, size=2000)
     pos[:3] = [0, b - a, 1]
+    edges = [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 3071, 3072, 3073, 6144, 24575, 24576]
+    pos[3:3 + len(edges)] = edges
     exp = np.array([ob.rank(int(c), int(p)) for c, p in zip(syms, pos)])
     assert (gb.rank(syms, pos) == exp).all()
     ranks = np.arange(a, b, 7)
