@@ -655,8 +655,7 @@ constexpr int BK_MASKS = BK_ITEMS * BK_WAVES;  // one 64-bit flag word per wave 
 
 template <bool SLACK>
 __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
-    k_bucket_emit(LeafEmit<PackedView> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before,
-                  int begin_bit) {
+    k_bucket_emit(LeafEmit<PackedView> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before) {
   __shared__ __align__(16) u64 buf[BK_CAP];
   __shared__ u64 tied_mask[BK_MASKS], slack_mask[SLACK ? BK_MASKS : 1];
   __shared__ u32 tied_pre[BK_MASKS + 1], slack_pre[SLACK ? BK_MASKS : 1];
@@ -944,7 +943,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
         KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
         if (e == b) {
           hipLaunchKernelGGL((k_bucket_emit<false>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
-                             (const u32 *)bs->start.get(), (const u32 *)nullptr, bs->begin_bit);
+                             (const u32 *)bs->start.get(), (const u32 *)nullptr);
           HIP_CHECK(hipGetLastError());
         } else {
           DBuf<u32> sb(c, BK_BUCKETS);
@@ -952,7 +951,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
           bucket_histogram(c, *tk, (u64)b, (u64)(e - b), 16, sb.get());
           scan_generic<u32, SumU32>(c, BK_BUCKETS, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, BK_BUCKETS});
           hipLaunchKernelGGL((k_bucket_emit<true>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
-                             (const u32 *)bs->start.get(), (const u32 *)sb.get(), bs->begin_bit);
+                             (const u32 *)bs->start.get(), (const u32 *)sb.get());
           HIP_CHECK(hipGetLastError());
         }
       }

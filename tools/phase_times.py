@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--sigma", type=int, default=4)
     ap.add_argument("--leaves", type=int, default=8)
     ap.add_argument("--level", type=int, default=2)
+    ap.add_argument("--seg", type=int, default=0)
     args = ap.parse_args()
     ctx = bwt_amd.Context(0)
     if args.kind == "repetitive":
@@ -51,12 +52,12 @@ def main():
         ctx.gen_text(n, 42, args.sigma)
     th = -(-n // args.leaves)
     ns = max(1000, n // 64)
-    ctx.pmbwt(th, ns, 0).free()
+    ctx.pmbwt(th, ns, args.seg).free()
     ctx.sync()
     ctx.set_timing(args.level)
     ctx.reset_timers()
     t0 = time.perf_counter()
-    ctx.pmbwt(th, ns, 0).free()
+    ctx.pmbwt(th, ns, args.seg).free()
     ctx.sync()
     dt = time.perf_counter() - t0
     print("n=%d leaves=%d: %.1f ms = %.1f Mbase/s" % (n, args.leaves, dt * 1e3, (n - 1) / dt / 1e6))
