@@ -339,14 +339,21 @@ struct LeafEmit : EmitParams {
   double samp_ratio; // (ns-1)/(m-1), only used to skip positions that are certainly not sampled
 
   // special ranks and samples of the suffix at `pos`, which has leaf rank r
+  // In two parts, because most positions are not sampled and the sampled ones of a wave's lanes rarely sit
+  // in the same iteration: note_fast() does the cheap part and says whether note_sample() has to look; a
+  // caller with several positions per lane collects those and looks at them afterwards, lanes together.
   __device__ __forceinline__ void note(u64 r, u32 pos) const {
+    if (note_fast(r, pos)) note_sample(r, pos);
+  }
+
+  __device__ __forceinline__ bool note_fast(u64 r, u32 pos) const {
     const u32 rel32 = pos - (u32)a;                // all positions are below 2^32
     if (rel32 == 0) special[0] = (u32)r;           // s_rank
     if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
     if (m == 1) {
       samp_rank[0] = (u32)r;
       samp_pos[0] = pos;
-      return;
+      return false;
     }
     // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
     // order, so the sample arrays come out sorted by position without a sort.  The two floor()
@@ -355,11 +362,13 @@ struct LeafEmit : EmitParams {
     // slow and most positions are not sampled: position i is sampled iff the fractional part of
     // i*(ns-1)/(m-1) is below (ns-1)/(m-1), so one multiplication (error far below the 2^-16
     // margin for any ns < 2^36) rules out the rest.
-    const i64 rel = (i64)rel32;
-    if (rel32 != 0) {
-      const double f = __builtin_amdgcn_fract((double)rel32 * samp_ratio);
-      if (f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16) return;
-    }
+    if (rel32 == 0) return true;
+    const double f = __builtin_amdgcn_fract((double)rel32 * samp_ratio);
+    return !(f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16);
+  }
+
+  __device__ __forceinline__ void note_sample(u64 r, u32 pos) const {
+    const i64 rel = (i64)(pos - (u32)a);
     i64 A = ns - 1;
     double D = (double)(i64)(m - 1);
     i64 x = (i64)floor((double)((rel - 1) * A) / D);
@@ -371,6 +380,14 @@ struct LeafEmit : EmitParams {
   }
 
   __device__ __forceinline__ u8 sym_before(u32 pos) const { return pos ? T[pos - 1] : T[n - 1]; }
+
+  // place() without the sample look-up; true if note_sample(r, pos) is still due
+  __device__ __forceinline__ bool place_fast(u64 r, u32 pos, u32 sym) const {
+    if (sa_out) sa_out[r] = pos;
+    if (!L) return false;
+    L[r] = (u8)sym;
+    return note_fast(r, pos);
+  }
 
   // the suffix at `pos` has leaf rank r and is preceded by `sym`
   __device__ __forceinline__ void place(u64 r, u32 pos, u32 sym) const {
@@ -778,6 +795,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   }
   lds_barrier();
   const u32 below = SLACK ? slack_before[blockIdx.x] : 0u;
+  u32 look = 0;  // bit r: the sample look-up of round r is still due
 #pragma unroll
   for (int r = 0; r < BK_ITEMS; r++) {
     const u32 idx = r * BK_THREADS + tid;
@@ -785,8 +803,17 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
       const u64 me = buf[idx];
       u32 sb = below;
       if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
-      E.place((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask), ((u32)me >> E.v.pbits) & 0xFFu);
+      if (E.place_fast((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask), ((u32)me >> E.v.pbits) & 0xFFu)) look |= 1u << r;
     }
+  }
+  while (look) {  // usually one pass per wave instead of one per round
+    const u32 r = __builtin_ctz(look);
+    look &= look - 1;
+    const u32 idx = r * BK_THREADS + tid;
+    const u64 me = buf[idx];
+    u32 sb = below;
+    if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
+    E.note_sample((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask));
   }
   const u32 all_tied = tied_pre[BK_MASKS];
   const BucketWindow win{E.v, buf, (u64)s, cnt};
