@@ -597,11 +597,16 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
   u32 tot;
   const u32 excl = block_scan_incl<OpSum>(mine, scan_s, &tot) - mine;
   const u32 carry = SLACK ? tile_slack[blockIdx.x] : 0u;
+  u32 look = 0;  // bit j: the sample look-up of rank i0 + j is still due
+  u32 rank_of[4] = {0, 0, 0, 0};
   if (!SLACK && whole && n_tied == 0) {
     if (E.sa_out) *reinterpret_cast<uint4 *>(E.sa_out + i0) = make_uint4(pos[0], pos[1], pos[2], pos[3]);
     if (E.L) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) E.note(i0 + j, pos[j]);
+      for (int j = 0; j < 4; j++) {
+        rank_of[j] = (u32)(i0 + j);
+        if (E.note_fast(i0 + j, pos[j])) look |= 1u << j;
+      }
       *reinterpret_cast<u32 *>(E.L + i0) = ((u32)full[0] & 0xFFu) | (((u32)full[1] & 0xFFu) << 8) |
                                            (((u32)full[2] & 0xFFu) << 16) | (((u32)full[3] & 0xFFu) << 24);
     }
@@ -613,10 +618,18 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
         tied_list[t_at++] = (u16)(tid * 4 + j);
         if (SLACK) slack_at[tid * 4 + j] = (u16)s_at;
       } else if (i0 + j < N && !slk[j]) {
-        E.place(i0 + j - (carry + s_at), pos[j], (u32)full[j] & 0xFFu);
+        rank_of[j] = (u32)(i0 + j - (carry + s_at));
+        if (E.place_fast(rank_of[j], pos[j], (u32)full[j] & 0xFFu)) look |= 1u << j;
       }
       s_at += slk[j];
     }
+  }
+  while (look) {  // the lanes' look-ups together: usually one pass per wave
+    const u32 j = __builtin_ctz(look);
+    look &= look - 1;
+    const u32 rk = j == 0 ? rank_of[0] : (j == 1 ? rank_of[1] : (j == 2 ? rank_of[2] : rank_of[3]));
+    const u32 ps = j == 0 ? pos[0] : (j == 1 ? pos[1] : (j == 2 ? pos[2] : pos[3]));
+    E.note_sample(rk, ps);
   }
   __syncthreads();
   const u32 all_tied = tot & 0xFFFFu;
