@@ -26,7 +26,7 @@ for mode in ("bucket", "plain"):
                 assert used > 0, key
                 res[key] = (sig, L.copy() if n < 1e7 else None)
             else:
-                assert used == 0 or n >= (1 << 26), (key, used)
+                assert used == 0 or n >= 100000000, (key, used)
                 assert res[key][0] == sig, key
                 if res[key][1] is not None:
                     assert (res[key][1] == L).all(), key
