@@ -199,6 +199,7 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
 struct BucketState {
   DBuf<u32> start;
   int begin_bit = 0;
+  u32 max_bucket = 0;  // elements of the largest bucket
   bool pending = false;
 };
 int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs);

@@ -680,7 +680,7 @@ static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n) {
 }
 
 // Bucket bounds of e (already sorted on its top 16 bits).  False if some bucket does not fit a workgroup.
-static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start) {
+static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start, u32 *max_bucket) {
   start = DBuf<u32>(c, BK_BUCKETS + 1);
   u32 *d_max = c.d_scalars + 12;
   {
@@ -692,6 +692,7 @@ static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start) {
   }
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();
+  *max_bucket = c.h_scalars[0];
   return c.h_scalars[0] <= (u32)BK_CAP;
 }
 
@@ -717,7 +718,7 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
     const int cur = leaf_sort_text_packed(c, elems, n, 48, text, nullptr);
     BucketState local;
     BucketState &st = bs ? *bs : local;
-    if (bucket_bounds(c, elems[cur], n, st.start)) {
+    if (bucket_bounds(c, elems[cur], n, st.start, &st.max_bucket)) {
       st.begin_bit = begin_bit;
       st.pending = true;
       if (!bs) bucket_sort_in_place(c, elems[cur], n, st);

@@ -681,20 +681,23 @@ __device__ __forceinline__ u32 select_bit(u64 m, u32 k) {
   return base;
 }
 
-constexpr int BK_MASKS = BK_ITEMS * BK_WAVES;  // one 64-bit flag word per wave and round
 
-template <bool SLACK>
+// ITEMS: elements per thread; the caller takes the smallest variant that holds the largest bucket, because
+// empty element slots still cost their instructions.
+template <bool SLACK, int ITEMS>
 __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     k_bucket_emit(LeafEmit<PackedView> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before) {
-  __shared__ __align__(16) u64 buf[BK_CAP];
+  constexpr int BK_MASKS = ITEMS * BK_WAVES;  // one 64-bit flag word per wave and round
+  constexpr int BUF_ELEMS = ITEMS * BK_THREADS > 6144 ? ITEMS * BK_THREADS : 6144;  // the counters need 48 KB
+  __shared__ __align__(16) u64 buf[BUF_ELEMS];
   __shared__ u64 tied_mask[BK_MASKS], slack_mask[SLACK ? BK_MASKS : 1];
   __shared__ u32 tied_pre[BK_MASKS + 1], slack_pre[SLACK ? BK_MASKS : 1];
   __shared__ u32 scan_s[4];
   static_assert(BK_MASKS <= 256, "the flag words are scanned by the first four waves");
-  const u32 s = start[blockIdx.x], cnt = start[blockIdx.x + 1] - s;  // cnt <= BK_CAP: the caller has checked
+  const u32 s = start[blockIdx.x], cnt = start[blockIdx.x + 1] - s;  // cnt <= ITEMS * BK_THREADS: the caller has checked
   if (cnt == 0) return;
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 wbase = w * BK_PER_WAVE;
+  const u32 wbase = w * (64 * ITEMS);
   const u64 *mine = E.v.e + s;
   {
     // Order of the bucket by the 16 key bits below the bucket's own (zero padding included when the key is
@@ -704,12 +707,12 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     // prefix sums of the counters per word, rank = keys below + own number.  A value that occurs more than
     // 15 times gives the direct pass up (the general path can order large groups).
     constexpr u32 NIB_WORDS = 8192;
-    static_assert(NIB_WORDS == 8 * BK_THREADS && NIB_WORDS * 4 + NIB_WORDS * 2 <= sizeof(u64) * BK_CAP, "counters fit the buffer");
+    static_assert(NIB_WORDS == 8 * BK_THREADS && NIB_WORDS * 4 + NIB_WORDS * 2 <= sizeof(u64) * BUF_ELEMS, "counters fit the buffer");
     u32 *nib = reinterpret_cast<u32 *>(buf);
     u16 *wpre = reinterpret_cast<u16 *>(nib + NIB_WORDS);  // counters in the words below word j
-    u64 key[BK_ITEMS];
+    u64 key[ITEMS];
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
       const u32 idx = wbase + r * 64 + lane;
       key[r] = idx < cnt ? mine[idx] : 0ull;
     }
@@ -720,7 +723,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     u64 ord = 0;  // 4 bits per element: its number among the elements of the same key
     bool full = false;
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
       if (wbase + r * 64 + lane < cnt) {
         const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
         const u32 old = (atomicAdd(&nib[k >> 3], 1u << sh) >> sh) & 15u;
@@ -755,9 +758,9 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
                      (base + run[4]) | ((base + run[5]) << 16), (base + run[6]) | ((base + run[7]) << 16));
     }
     lds_barrier();
-    u32 pos[BK_ITEMS];
+    u32 pos[ITEMS];
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
       const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
       const u32 below = nib[k >> 3] & ((1u << sh) - 1u);
       const u32 y = (below & 0x0F0F0F0Fu) + ((below >> 4) & 0x0F0F0F0Fu);
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     }
     lds_barrier();  // the counters are dead: the buffer takes the elements
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++)
+    for (int r = 0; r < ITEMS; r++)
       if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
     lds_barrier();
   }
@@ -774,7 +777,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   const u32 *hiw = reinterpret_cast<const u32 *>(buf) + 1;  // hiw[2 * i]: high word of element i
   u32 tied_bits = 0, slack_bits = 0;
 #pragma unroll
-  for (int r = 0; r < BK_ITEMS; r++) {
+  for (int r = 0; r < ITEMS; r++) {
     const u32 idx = r * BK_THREADS + tid;
     bool tied = false, sl = false;
     if (idx < cnt) {
@@ -795,7 +798,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   {
     const u32 tc = tid < BK_MASKS ? (u32)__popcll(tied_mask[tid]) : 0u;
     const u32 sc = (SLACK && tid < BK_MASKS) ? (u32)__popcll(slack_mask[tid]) : 0u;
-    const u32 both = tc | (sc << 16);  // either total is at most BK_CAP
+    const u32 both = tc | (sc << 16);  // either total is at most ITEMS * BK_THREADS
     u32 incl = wave_scan_incl_sum(both);
     if (lane == 63 && w < 4) scan_s[w] = incl;
     lds_barrier();
@@ -810,7 +813,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   const u32 below = SLACK ? slack_before[blockIdx.x] : 0u;
   u32 look = 0;  // bit r: the sample look-up of round r is still due
 #pragma unroll
-  for (int r = 0; r < BK_ITEMS; r++) {
+  for (int r = 0; r < ITEMS; r++) {
     const u32 idx = r * BK_THREADS + tid;
     if (idx < cnt && !((tied_bits >> r) & 1) && !((slack_bits >> r) & 1)) {
       const u64 me = buf[idx];
@@ -942,6 +945,18 @@ static KeyPlan plan_keys(int span, int raw_bits, u64 N) {  // span = max_sym - m
   return best;
 }
 
+template <bool SLACK>
+static void launch_bucket_emit(Ctx &c, const LeafEmit<PackedView> &em, u32 max_bucket, const u32 *start, const u32 *slack_before) {
+  const u32 items = ceil_div(max_bucket ? max_bucket : 1, BK_THREADS);
+  if (items > (u32)BK_ITEMS) fail(BWT_HIP_EINTERNAL, "bucket of %u elements", max_bucket);
+  const dim3 grid(BK_BUCKETS), block(BK_THREADS);
+  if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items <= 6) hipLaunchKernelGGL((k_bucket_emit<SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items <= 8) hipLaunchKernelGGL((k_bucket_emit<SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);
+  else hipLaunchKernelGGL((k_bucket_emit<SLACK, BK_ITEMS>), grid, block, 0, c.stream, em, start, slack_before);
+  HIP_CHECK(hipGetLastError());
+}
+
 // Everything after the round-0 sort: tie list, refinement, emit.  sa_w: the writable positions (pairs
 // layout) or null; e_w: the writable elements (packed layout) or null.  scratch: 2N free 32-bit words for
 // the first active list; grp_buf: N more words (pairs: the unused value buffer).
@@ -982,17 +997,13 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
         from_buckets = true;
         KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
         if (e == b) {
-          hipLaunchKernelGGL((k_bucket_emit<false>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
-                             (const u32 *)bs->start.get(), (const u32 *)nullptr);
-          HIP_CHECK(hipGetLastError());
+          launch_bucket_emit<false>(c, em, bs->max_bucket, bs->start.get(), nullptr);
         } else {
           DBuf<u32> sb(c, BK_BUCKETS);
           HIP_CHECK(hipMemsetAsync(sb.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
           bucket_histogram(c, *tk, (u64)b, (u64)(e - b), 16, sb.get());
           scan_generic<u32, SumU32>(c, BK_BUCKETS, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, BK_BUCKETS});
-          hipLaunchKernelGGL((k_bucket_emit<true>), dim3(BK_BUCKETS), dim3(BK_THREADS), 0, c.stream, em,
-                             (const u32 *)bs->start.get(), (const u32 *)sb.get());
-          HIP_CHECK(hipGetLastError());
+          launch_bucket_emit<true>(c, em, bs->max_bucket, bs->start.get(), sb.get());
         }
       }
     }
