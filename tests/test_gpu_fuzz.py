@@ -1,0 +1,39 @@
+"""A short differential run over random small configurations (tools/fuzz_small.py holds the generator): text shape,
+alphabet and its offset, leaf size, sample count and chain length all vary; everything is compared with the oracle."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from tests.gpu_util import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _generator():
+    spec = importlib.util.spec_from_file_location("fuzz_small", os.path.join(os.path.dirname(HERE), "tools", "fuzz_small.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.make
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_small_configurations(ctx, seed):
+    make = _generator()
+    rng = np.random.default_rng(seed)
+    for k in range(60):
+        T, amax, th, ns, seg, kind = make(rng)
+        n = len(T)
+        tag = "seed %d case %d: n=%d max_sym=%d th=%d ns=%d seg=%d %s" % (seed, k, n, amax, th, ns, seg, kind)
+        ctx.set_text(T)
+        blk = ctx.pmbwt(th, ns, seg)
+        o = Oracle.opt(n, alpha_min=1, alpha_max=amax, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+        ob = Oracle.pmbwt(T, o)
+        assert (blk.L == ob.L).all(), tag
+        assert (blk.s_rank, blk.e_rank, blk.e_char) == (ob.s_rank, ob.e_rank, ob.e_char), tag
+        for x, y in zip(blk.samples(), ob.samples()):
+            assert len(x) == len(y) and (x == y).all(), tag
+        blk.free()
