@@ -3,6 +3,7 @@
 //   independent: the next index comes from the lane's own generator (as many reads in flight as the hardware takes)
 //   dependent:   the next index depends on the data just read (one read in flight per lane, like an LF step)
 // usage: random_sector_rate [table_MB=167] [threads=500000] [steps=1024]
+//        random_sector_rate stream      (a plain copy, for the streaming rate of the same chip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -81,7 +82,62 @@ __global__ void __launch_bounds__(256) k_reads(const uint4 *__restrict__ table, 
   if (acc == 0xFFFFFFFFu) sink[0] = acc;
 }
 
+// plain streaming copy, 16 bytes per lane: what the chip gives a kernel that only streams
+__global__ void __launch_bounds__(256) k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) k_read(const uint4 *__restrict__ src, size_t n16, uint32_t *__restrict__ sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0xFFFFFFFFu) sink[0] = acc;
+}
+
+static void stream_rate() {
+  const size_t bytes = (size_t)2 << 30;
+  uint4 *a, *b;
+  CHECK(hipMalloc(&a, bytes));
+  CHECK(hipMalloc(&b, bytes));
+  CHECK(hipMemset(a, 1, bytes));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; rep++) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_copy, dim3(256 * 32), dim3(256), 0, 0, a, b, bytes / 16);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("streaming copy of 2 GiB (read + write 4 GiB): %.3f ms = %.2f TB/s\n", best, 2.0 * bytes / (best * 1e-3) / 1e12);
+  best = 1e30f;
+  for (int rep = 0; rep < 5; rep++) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_read, dim3(256 * 32), dim3(256), 0, 0, a, bytes / 16, (uint32_t *)b);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("streaming read of 2 GiB: %.3f ms = %.2f TB/s\n", best, 1.0 * bytes / (best * 1e-3) / 1e12);
+  CHECK(hipFree(a));
+  CHECK(hipFree(b));
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == 's') {
+    stream_rate();
+    return 0;
+  }
   const size_t mb = argc > 1 ? strtoull(argv[1], 0, 10) : 167;
   const uint32_t threads = argc > 2 ? (uint32_t)strtoul(argv[2], 0, 10) : 500000;
   const int steps = argc > 3 ? atoi(argv[3]) : 1024;
