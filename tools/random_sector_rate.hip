@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(256) k_read(const uint4 *__restrict__ src, siz
   if (acc == 0xFFFFFFFFu) sink[0] = acc;
 }
 
+__global__ void __launch_bounds__(256) k_write(uint4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    dst[i] = make_uint4((uint32_t)i, 1, 2, 3);
+}
+
 static void stream_rate() {
   const size_t bytes = (size_t)2 << 30;
   uint4 *a, *b;
@@ -129,6 +134,18 @@ static void stream_rate() {
     if (ms < best) best = ms;
   }
   printf("streaming read of 2 GiB: %.3f ms = %.2f TB/s\n", best, 1.0 * bytes / (best * 1e-3) / 1e12);
+  best = 1e30f;
+  for (int rep = 0; rep < 5; rep++) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_write, dim3(256 * 32), dim3(256), 0, 0, b, bytes / 16);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("streaming write of 2 GiB: %.3f ms = %.2f TB/s\n", best, 1.0 * bytes / (best * 1e-3) / 1e12);
   CHECK(hipFree(a));
   CHECK(hipFree(b));
 }
