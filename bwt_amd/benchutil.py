@@ -4,6 +4,9 @@ import os
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec sheet); a plain copy kernel reaches about 6300 GB/s
 SECTOR = 64            # bytes the memory side moves for one random rank-block read
+# isolated random 64-byte reads per second this chip serves, whatever the kernel around them does
+# (tools/random_sector_rate.hip, results under profiles/): the ceiling of the LF chains' access shape
+RANDOM_READS_PER_S = 5.6e10
 
 # Kernels that can dominate a build: (timer, kernel, what the timer's `work` counts, algorithmic unit).
 #   bytes:   `work` is algorithmic bytes summed over launches
@@ -55,6 +58,10 @@ def roofline(timers, repo_root=None, workload=None):
             if t.get("workload") == workload and name in t.get("kernels", {}):
                 roof["traffic"] = t["kernels"][name]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r1_traffic.json"
+    if kind == "sectors":
+        roof["random_read_ceiling"] = {"reads_per_s": RANDOM_READS_PER_S, "achieved_reads_per_s": round(work / (ms * 1e-3), 1),
+                                       "frac": round(work / (ms * 1e-3) / RANDOM_READS_PER_S, 4),
+                                       "source": "profiles/r1_random_sector_rate.txt (tools/random_sector_rate.hip)"}
     roof["others"] = [{"kernel": d[1], "ms_total": round(timers[d[0]][0], 3), "launches": timers[d[0]][2],
                        "achieved": round(_rate(timers, d[0], d[2]), 1),
                        "frac": round(_rate(timers, d[0], d[2]) / HBM_PEAK_GBS, 4)} for d in found[1:]]
