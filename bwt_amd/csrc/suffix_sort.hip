@@ -9,6 +9,10 @@
 //             the fly.  Two layouts (TextKeys in internal.h): (key, position)
 //             pairs of 12 bytes, or -- small alphabets, windows below 2^29 --
 //             one 8-byte element holding codes, preceding symbol and position
+//   buckets   large windows of 8-byte elements stop the radix sort after the top 16
+//             key bits: a bucket (equal top 16 bits) fits LDS, where one workgroup
+//             orders it on the remaining bits and does the direct pass below
+//             without the sorted window ever going back to memory (k_bucket_emit)
 //   direct    one pass that ends the sort on texts without long repeats: a suffix
 //             whose key is unique is final; one that shares its key counts the
 //             members of its (small) group that are smaller by comparing the text
