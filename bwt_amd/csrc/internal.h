@@ -186,6 +186,11 @@ struct TextKeys {
   // 0: (key, value) pairs as above.  Otherwise PACKED 8-byte elements (K0 * w <= 32, window below 2^pbits):
   //   | codes, 32 bits | T[a+i-1], 32 - pbits bits | i, pbits bits |
   int pbits;
+  // Packed elements only: if not null, the pass that builds the elements also writes the next pass's digit of
+  // every element (bits next_shift .. next_shift+7) into this byte array, in output order, so that the next
+  // pass's histogram reads one byte per element instead of eight.
+  u8 *next_digits;
+  int next_shift;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).

@@ -234,7 +234,8 @@ template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE, bool ANY_
 __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
                                                 u32 *gbase, u32 *scan_s, K *__restrict__ kout,
                                                 u32 *__restrict__ vout, u32 tile_n, int shift, u32 mask,
-                                                const u32 *__restrict__ offs, u32 nblk, u32 tile, u32 stride) {
+                                                const u32 *__restrict__ offs, u32 nblk, u32 tile, u32 stride,
+                                                u8 *__restrict__ next_digits = nullptr, int next_shift = 0) {
   u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * 256;
   K *keys_s = reinterpret_cast<K *>(buf);
@@ -342,6 +343,9 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
         klo[(size_t)stride + dst] = (u32)((u64)k >> 32);  // beyond 2^32 words for windows above 2^31
       } else {
         kout[dst] = k;
+        if constexpr (REVERSE && sizeof(K) == 8) {  // the text pass: the next pass's digits on the side
+          if (next_digits) next_digits[dst] = (u8)((u64)k >> next_shift);
+        }
       }
       if (HAS_VALS) vout[dst] = vals_s[p];
     }
@@ -452,10 +456,39 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   }
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
-                                              tile, stride);
+                                              tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
-                                               nblk, tile, stride);
+                                               nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift);
+}
+
+// tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
+__global__ void __launch_bounds__(RH_THREADS)
+    k_rs_hist_bytes(const u8 *__restrict__ digits, size_t n, u32 *__restrict__ counts, u32 nblk) {
+  __shared__ u32 cnt[RH_THREADS / 64][256];
+  static_assert(RS_TILE == RH_THREADS * 16, "one 16-byte load per thread covers the tile");
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
+  const u32 tile = xcd_tile(blockIdx.x, nblk);
+  const size_t i0 = (size_t)tile * RS_TILE + (size_t)tid * 16;
+  __builtin_amdgcn_wave_barrier();
+  if (i0 + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(digits + i0);
+    const u32 wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) atomicAdd(&cnt[w][(wd[q] >> (8 * b)) & 255u], 1u);
+  } else {
+    for (size_t i = i0; i < n && i < i0 + 16; i++) atomicAdd(&cnt[w][digits[i]], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
+    counts[(size_t)tid * nblk + tile] = tot;
+  }
 }
 
 template <class K, int USE>
@@ -730,6 +763,16 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
   DBuf<u32> counts(c, (size_t)256 * nblk);
   TextKeys none;
   memset(&none, 0, sizeof(none));
+  // the text pass leaves the second pass's digits in a byte array of their own: its histogram then reads one
+  // byte per element instead of the whole element
+  DBuf<u8> digits;
+  TextKeys first = text;
+  first.next_digits = nullptr;
+  if (begin_bit + 8 < 64) {
+    digits = DBuf<u8>(c, n);
+    first.next_digits = digits.get();
+    first.next_shift = begin_bit + 8;
+  }
   int cur = 0;
   for (int shift = begin_bit; shift < 64; shift += 8) {
     const u32 mask = 255u;
@@ -737,7 +780,7 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
       {
         KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
         hipLaunchKernelGGL((k_rs_hist<u64, 0, true>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr,
-                           n, shift, mask, counts.get(), nblk, text);
+                           n, shift, mask, counts.get(), nblk, first);
         HIP_CHECK(hipGetLastError());
       }
       scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
@@ -745,11 +788,16 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
         KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
         hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                            (const u64 *)nullptr, (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask,
-                           counts.get(), nblk, text, 0u);
+                           counts.get(), nblk, first, 0u);
         HIP_CHECK(hipGetLastError());
       }
     } else {
-      {
+      if (shift == begin_bit + 8 && digits.get()) {
+        KernelTimer kt(c, "leaf:k_rs_hist_bytes", (double)n);
+        hipLaunchKernelGGL(k_rs_hist_bytes, dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u8 *)digits.get(), n,
+                           counts.get(), nblk);
+        HIP_CHECK(hipGetLastError());
+      } else {
         KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
         hipLaunchKernelGGL((k_rs_hist<u64, 0, false>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, elems[cur], n, shift,
                            mask, counts.get(), nblk, none);
