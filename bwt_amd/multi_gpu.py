@@ -143,7 +143,14 @@ def bench_main(args, rank, local_rank, world):
     n = args.n if args.n_given else 3100000000
     ctx = bwt_amd.Context(local_rank)
     ctx.gen_text(n, 42, args.sigma)
-    lpr = max(1, args.leaves // 2) if args.leaves_given else 1
+    if args.leaves_given:
+        lpr = max(1, args.leaves // 2)
+    else:
+        # One leaf per GPU, except where halving a GPU's share brings the leaves under 2^29 suffixes: there the
+        # 8-byte elements and the bucket route of the leaf sort beat one leaf of key + position pairs even with
+        # the local merge added (7.75e8 suffixes: about 26 ms against 32 ms).
+        share = n // world
+        lpr = 2 if (1 << 29) < share + share // 256 <= (1 << 30) else 1
     total_leaves = world * lpr
     depth = total_leaves.bit_length() - 1
     ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
