@@ -134,6 +134,12 @@ def pmbwt_tree(ops, rank, world, n, leaves_per_rank, dist, hdr_device="cpu", fre
 
 def bench_main(args, rank, local_rank, world):
     """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs."""
+    # RCCL prints a version banner on standard output when its first communicator comes up.  This program's
+    # standard output is one JSON line: descriptor 1 points at stderr from here on, the line goes out through
+    # a copy of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import bwt_amd
@@ -224,8 +230,9 @@ def bench_main(args, rank, local_rank, world):
             "roofline": roofline(timers), "cpu_baseline": None,
             "phases_rank0": phase_table(timers, args.steps),
         }
-        print(json.dumps(out))
-        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # whatever C code still holds in its buffers goes to stderr first
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if last is not None:
         last.free()
     ctx.close()
