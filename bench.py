@@ -8,8 +8,9 @@ already resident in HBM; the result L stays in HBM.  Metric: Mbase/s = (n-1) / s
 
 N = 1 runs the configuration the headline metric is quoted on for one GPU: random DNA, n = 1e9, two leaves
 of 5e8 and one gap-array merge.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the ranks share
-ONE text of 3.1e9 symbols: each builds the leaves of its part and the blocks are merged pairwise over RCCL
-send/recv (bwt_amd/multi_gpu.py); that is strong scaling.
+ONE text of 3.1e9 symbols: each builds the leaves of its part, and every merge of the tree runs on all GPUs of its
+subtree, exchanging chain heads, gap counts and block slices over RCCL (bwt_amd/multi_gpu.py, bwt_amd/dist_merge.py);
+that is strong scaling.
 
 Prints ONE JSON line on rank 0.
 """

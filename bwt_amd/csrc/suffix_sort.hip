@@ -723,6 +723,10 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     reinterpret_cast<uint4 *>(nib)[tid * 2] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4 *>(nib)[tid * 2 + 1] = make_uint4(0, 0, 0, 0);
     if (tid == 0) scan_s[3] = 0;
+    if (tid < BK_MASKS) {
+      tied_mask[tid] = 0;
+      if (SLACK) slack_mask[tid] = 0;
+    }
     lds_barrier();
     u64 ord = 0;  // 4 bits per element: its number among the elements of the same key
     bool full = false;
@@ -762,43 +766,33 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
                      (base + run[4]) | ((base + run[5]) << 16), (base + run[6]) | ((base + run[7]) << 16));
     }
     lds_barrier();
-    u32 pos[ITEMS];
+    // All elements of the bucket share the 16 key bits above these, and the bits below the symbol codes are
+    // zero: two elements have the same key exactly when they share a counter.  So the counter also says
+    // whether an element is tied, and the flag words -- bit i: the element at sorted index i is tied / is
+    // window slack -- are set from here, by the few elements that are either.
+    u32 pos[ITEMS], tied_in = 0;
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
       const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
-      const u32 below = nib[k >> 3] & ((1u << sh) - 1u);
+      const u32 word = nib[k >> 3];
+      const u32 below = word & ((1u << sh) - 1u);
       const u32 y = (below & 0x0F0F0F0Fu) + ((below >> 4) & 0x0F0F0F0Fu);
       pos[r] = wpre[k >> 3] + ((y * 0x01010101u) >> 24) + ((u32)(ord >> (4 * r)) & 15u);
+      tied_in |= (u32)(((word >> sh) & 15u) > 1u) << r;
     }
     lds_barrier();  // the counters are dead: the buffer takes the elements
+    u32 *tied32 = reinterpret_cast<u32 *>(tied_mask), *slack32 = reinterpret_cast<u32 *>(slack_mask);
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++)
-      if (wbase + r * 64 + lane < cnt) buf[pos[r]] = key[r];
+    for (int r = 0; r < ITEMS; r++) {
+      if (wbase + r * 64 + lane < cnt) {
+        buf[pos[r]] = key[r];
+        if ((tied_in >> r) & 1u) atomicOr(&tied32[pos[r] >> 5], 1u << (pos[r] & 31u));
+        if (SLACK && E.v.a + ((u32)key[r] & E.v.posmask) >= E.leaf_end) atomicOr(&slack32[pos[r] >> 5], 1u << (pos[r] & 31u));
+      }
+    }
     lds_barrier();
   }
-  // flags: thread t looks at the sorted indices r * 1024 + t, so flag word r * 16 + w covers 64 consecutive ones
-  const u32 mask_hi = (u32)(E.sym_mask >> 32);  // the symbol codes are the high word of an element
-  const u32 *hiw = reinterpret_cast<const u32 *>(buf) + 1;  // hiw[2 * i]: high word of element i
-  u32 tied_bits = 0, slack_bits = 0;
-#pragma unroll
-  for (int r = 0; r < ITEMS; r++) {
-    const u32 idx = r * BK_THREADS + tid;
-    bool tied = false, sl = false;
-    if (idx < cnt) {
-      const u32 km = hiw[2 * idx] & mask_hi;
-      tied = (idx > 0 && (hiw[2 * idx - 2] & mask_hi) == km) || (idx + 1 < cnt && (hiw[2 * idx + 2] & mask_hi) == km);
-      sl = SLACK && E.v.a + (hiw[2 * idx - 1] & E.v.posmask) >= E.leaf_end;
-    }
-    const u64 tm = __ballot(tied);
-    tied_bits |= (u32)tied << r;
-    if (lane == 0) tied_mask[r * BK_WAVES + w] = tm;
-    if (SLACK) {
-      const u64 sm = __ballot(sl);
-      slack_bits |= (u32)sl << r;
-      if (lane == 0) slack_mask[r * BK_WAVES + w] = sm;
-    }
-  }
-  lds_barrier();
+  // thread t emits the sorted indices r * 1024 + t; flag word r * 16 + w covers those of wave w in round r
   {
     const u32 tc = tid < BK_MASKS ? (u32)__popcll(tied_mask[tid]) : 0u;
     const u32 sc = (SLACK && tid < BK_MASKS) ? (u32)__popcll(slack_mask[tid]) : 0u;
@@ -816,10 +810,14 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   lds_barrier();
   const u32 below = SLACK ? slack_before[blockIdx.x] : 0u;
   u32 look = 0;  // bit r: the sample look-up of round r is still due
+  const u32 *flag32 = reinterpret_cast<const u32 *>(tied_mask), *sflag32 = reinterpret_cast<const u32 *>(slack_mask);
+  const u32 my_bit = 1u << (tid & 31u);
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const u32 idx = r * BK_THREADS + tid;
-    if (idx < cnt && !((tied_bits >> r) & 1) && !((slack_bits >> r) & 1)) {
+    u32 flags = flag32[idx >> 5];
+    if (SLACK) flags |= sflag32[idx >> 5];
+    if (idx < cnt && !(flags & my_bit)) {
       const u64 me = buf[idx];
       u32 sb = below;
       if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
