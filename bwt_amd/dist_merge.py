@@ -285,6 +285,32 @@ def make_groups(dist, world):
     return groups
 
 
+def warm_groups(dist, groups, rank, world, device, host_staging):
+    """One tiny call of every collective a merge uses, on each group this rank belongs to: the transport sets up its
+    communicators and peer connections at first use, which is set-up cost and not part of a build."""
+    import torch
+    dev = "cpu" if host_staging else device
+    G = 2
+    while G <= world:
+        i = rank // G
+        comm = Comm(dist, groups[G][i], range(i * G, (i + 1) * G), rank, dev, False)
+        comm.all_gather_i64([rank])
+        got = comm.all_to_all(torch.full((G,), rank, dtype=torch.int32, device=dev), [1] * G, [1] * G)
+        if [int(x) for x in got.cpu().tolist()] != list(comm.ranks):
+            raise RuntimeError("all-to-all warm-up returned %r on rank %d" % (got.cpu().tolist(), rank))
+        out = torch.zeros(G, dtype=torch.uint8, device=dev)
+        mine = torch.full((1,), comm.k + 1, dtype=torch.uint8, device=dev)
+        comm.spread([mine if r == rank else None for r in comm.ranks], out, list(range(G + 1)))
+        if [int(x) for x in out.cpu().tolist()] != list(range(1, G + 1)):
+            raise RuntimeError("point-to-point warm-up returned %r on rank %d" % (out.cpu().tolist(), rank))
+        t = torch.ones(1, dtype=torch.int32, device=dev)
+        comm.broadcast(t, comm.ranks[0])
+        comm.sum_to(t, comm.ranks[0])
+        G *= 2
+    if not host_staging and getattr(device, "type", str(device)) == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def pmbwt_dist(ops, rank, world, n, leaves_per_rank, dist, groups, device, host_staging):
     """The whole BWT of [0,n) over `world` ranks; returns this rank's DistBlock of the final block (slice `rank` of L;
     samples and special ranks on rank 0)."""

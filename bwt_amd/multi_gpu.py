@@ -167,6 +167,7 @@ def bench_main(args, rank, local_rank, world):
         from bwt_amd import dist_merge
         dops = dist_merge.HipDistOps(ctx, ns, args.seg, dev)
         groups = dist_merge.make_groups(dist, world)
+        dist_merge.warm_groups(dist, groups, rank, world, dev, False)  # communicator set-up, also with --warmup 0
 
         class _Held:  # what a step leaves behind: this rank's slice (torch frees it with the object)
             def __init__(self, d):

@@ -216,6 +216,7 @@ def main():
             ops = NumpyDistOps(T, opt, args.ns, args.seg, th)
         groups = dist_merge.make_groups(dist, world)
         staging = not args.direct
+        dist_merge.warm_groups(dist, groups, rank, world, dev, staging)
         blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, staging)
         L = dist_merge.gather_L(blk, rank, world, dist, dev, staging)
         if rank == 0:
