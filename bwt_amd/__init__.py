@@ -70,6 +70,7 @@ def lib():
         "bwt_hip_dist_chains": [vp, vp, i64, i64, i64, vp],
         "bwt_hip_dist_partition": [vp, vp, i64, i64, i32, vp, _i64p],
         "bwt_hip_dist_merge_slice": [vp, vp, i64, vp, i64, vp, vp, vp],
+        "bwt_hip_dist_merge_slice_noalloc": [vp, vp, i64, vp, i64, vp, vp, vp],
         "bwt_hip_dist_resample": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, vp, vp, _i64p],
         "bwt_hip_set_timing": [vp, i32],
         "bwt_hip_reset_timers": [vp],
@@ -215,6 +216,10 @@ class Context:
     def dist_merge_slice(self, lL_ptr, mL, rL_ptr, rn, g_ptr, out_ptr, S_ptr):
         _chk(lib().bwt_hip_dist_merge_slice(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),
                                             C.c_void_p(out_ptr), C.c_void_p(S_ptr)))
+
+    def dist_merge_slice_noalloc(self, lL_ptr, mL, rL_ptr, rn, g_ptr, out_ptr, S_ptr):
+        _chk(lib().bwt_hip_dist_merge_slice_noalloc(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),
+                                                    C.c_void_p(out_ptr), C.c_void_p(S_ptr)))
 
     def dist_resample(self, l_rank_ptr, l_pos_ptr, nl, r_rank_ptr, r_pos_ptr, nr, a, c, ns_out, S_ptr, i_lo, i_hi,
                       right_before, g_ptr, p_lo, p_hi, o_rank_ptr, o_pos_ptr):

@@ -63,6 +63,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   HIP_CHECK(hipHostMalloc((void **)&c.h_scalars, 64 * sizeof(u32), hipHostMallocDefault));
   HIP_CHECK(hipMalloc((void **)&c.d_scalars, 64 * sizeof(u32)));
   if (const char *v = getenv("BWT_HIP_BUCKET_MIN_N")) c.bucket_min_n = strtoull(v, nullptr, 10);  // tuning and tests
+  (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current
   *out = h.release();
   API_END
 }
@@ -535,6 +536,27 @@ int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL
   gap_prefix(c, g_dev, scratch.get(), (u64)rn, (u64)mL, S_dev);
   merge_symbols(c, lL_dev, (u64)mL, rL_dev, (u64)rn, S_dev, out_dev);
   c.sync();
+  API_END
+}
+
+int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev,
+                                     int64_t rn, uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev) {
+  API_BEGIN
+  need(ctx && S_dev && mL >= 0 && rn >= 0, "ctx, S_dev, mL >= 0, rn >= 0");
+  need((mL == 0 || lL_dev) && (rn == 0 || (rL_dev && g_dev)) && (mL + rn == 0 || out_dev), "device buffers");
+  need(mL + rn < (int64_t)((1ull << 32) - 2), "slice below 2^32-2 symbols");
+  if (rn > (int64_t)BWT_HIP_NOALLOC_MAX_RIGHT)
+    fail(BWT_HIP_EINVAL, "bwt_hip_dist_merge_slice_noalloc: rn = %ld exceeds the %ld right symbols the static scratch holds",
+         (long)rn, (long)BWT_HIP_NOALLOC_MAX_RIGHT);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  {
+    ArenaScope arena(c);  // the sort's second buffer, tile counts and scan partials come out of the static array
+    DBuf<u32> second(c, (size_t)(rn > 0 ? rn : 1));
+    gap_prefix(c, g_dev, second.get(), (u64)rn, (u64)mL, S_dev);
+    merge_symbols(c, lL_dev, (u64)mL, rL_dev, (u64)rn, S_dev, out_dev);
+    c.sync();
+  }
   API_END
 }
 

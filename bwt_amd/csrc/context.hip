@@ -1,6 +1,8 @@
 // Device context: caching allocator, phase timers, text utilities.
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "internal.h"
 #include "device_utils.h"
 
@@ -27,7 +29,46 @@ static size_t round_size(size_t b) {
   return (b + ((1u << 21) - 1)) & ~(size_t)((1u << 21) - 1);
 }
 
+// ---------------------------------------------------------------------------
+// Scratch memory of the entry points that must not allocate (bwt_hip_dist_merge_slice_noalloc): one static
+// array per GPU, held from the moment the library's code is loaded on it until the process ends.  In host
+// code the array's name is only a handle for hipGetSymbolAddress: every use of the memory -- kernel
+// arguments, memsets, copies -- goes through the address looked up here, once per device with that
+// device current (each GPU has its own copy at its own address).
+// ---------------------------------------------------------------------------
+constexpr size_t SCRATCH_BYTES = (size_t)20 << 20;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static unsigned char *g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+unsigned char *device_scratch(int device, size_t *bytes) {
+  if (device < 0 || device >= MAX_DEVICES) fail(BWT_HIP_EINVAL, "device %d: at most %d devices", device, MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    int cur = -1;
+    HIP_CHECK(hipGetDevice(&cur));
+    if (cur != device) fail(BWT_HIP_EINTERNAL, "scratch look-up for device %d while device %d is current", device, cur);
+    void *p = nullptr;
+    HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p || ((uintptr_t)p & 255)) fail(BWT_HIP_EINTERNAL, "scratch array of device %d at %p", device, p);
+    g_scratch_ptr[device] = (unsigned char *)p;
+  }
+  if (bytes) *bytes = SCRATCH_BYTES;
+  return g_scratch_ptr[device];
+}
+
 void *Ctx::alloc(size_t bytes) {
+  if (arena_on) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > arena_cap - arena_used)
+      fail(BWT_HIP_EINVAL, "no-alloc call needs %zu more bytes of scratch than the %zu the library holds", need - (arena_cap - arena_used),
+           arena_cap);
+    void *p = arena + arena_used;
+    arena_used += need;
+    return p;
+  }
   size_t sz = round_size(bytes);
   auto it = free_blocks.lower_bound(sz);
   void *p = nullptr;
@@ -54,6 +95,7 @@ void *Ctx::alloc(size_t bytes) {
 
 void Ctx::release(void *p) {
   if (!p) return;
+  if (arena && (unsigned char *)p >= arena && (unsigned char *)p < arena + arena_cap) return;  // part of the static array
   auto it = live_blocks.find(p);
   if (it == live_blocks.end()) return;
   size_t sz = it->second;

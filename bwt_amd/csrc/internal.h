@@ -91,6 +91,13 @@ struct Ctx {
   u32 *h_scalars = nullptr;  // 64 words, pinned
   u32 *d_scalars = nullptr;  // 64 words, device
 
+  // While `arena_on` is set, alloc() carves its blocks out of [arena, arena + arena_cap) -- this GPU's copy of
+  // the library's static device array -- and never reaches the driver; release() of such a block does
+  // nothing.  ArenaScope turns it on for the duration of one call.
+  unsigned char *arena = nullptr;
+  size_t arena_cap = 0, arena_used = 0;
+  bool arena_on = false;
+
   void *alloc(size_t bytes);
   void release(void *p);
   void trim();  // return cached blocks to the driver
@@ -128,6 +135,27 @@ struct DBuf {
   }
   T *get() const { return p; }
   operator T *() const { return p; }
+};
+
+// This GPU's copy of the library's static device array (context.hip) and its size.  The address is looked up
+// once per device, with that device current; the array's name itself is never used as an address.
+unsigned char *device_scratch(int device, size_t *bytes);
+
+// All pool allocations inside the scope come from the static device array; phase timing (which creates
+// events) is off.  The array is shared by every call on the GPU and keeps the last call's contents.
+struct ArenaScope {
+  Ctx &c;
+  int saved_timing;
+  explicit ArenaScope(Ctx &ctx) : c(ctx), saved_timing(ctx.timing_level) {
+    c.arena = device_scratch(c.device, &c.arena_cap);
+    c.arena_used = 0;
+    c.arena_on = true;
+    c.timing_level = 0;
+  }
+  ~ArenaScope() {
+    c.arena_on = false;
+    c.timing_level = saved_timing;
+  }
 };
 
 // scoped phase timer: records two events on the stream when timing is on
