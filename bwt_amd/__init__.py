@@ -66,6 +66,8 @@ def lib():
         "bwt_hip_block_rank": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_block_LF": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
+        "bwt_hip_block_ibwt": [vp, vp, _u8p, _i64p],
+        "bwt_hip_block_sa": [vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dist_bounds": [i64, i32, _i64p],
         "bwt_hip_dist_chains": [vp, vp, i64, i64, i64, vp],
         "bwt_hip_dist_partition": [vp, vp, i64, i64, i32, vp, _i64p],
@@ -332,6 +334,25 @@ class Block:
 
     def init_extra(self):
         _chk(lib().bwt_hip_block_init_extra(self.ctx._h, self._h))
+
+    def ibwt(self):
+        """T[a:b) decoded from L on the device (bwt::ibwt)."""
+        out = np.empty(self.b - self.a, dtype=np.uint8)
+        _chk(lib().bwt_hip_block_ibwt(self.ctx._h, self._h, _p(out, _u8p), None))
+        return out
+
+    def ibwt_mismatches(self):
+        """Positions where the decoded block differs from the context's text (0 = round trip ok); nothing is downloaded."""
+        bad = C.c_int64(-1)
+        _chk(lib().bwt_hip_block_ibwt(self.ctx._h, self._h, None, C.byref(bad)))
+        return bad.value
+
+    def sa(self, rank):
+        """SA[r] for absolute ranks r (bwt::sa)."""
+        rank = np.ascontiguousarray(rank, dtype=np.int64)
+        out = np.empty(len(rank), dtype=np.int64)
+        _chk(lib().bwt_hip_block_sa(self.ctx._h, self._h, len(rank), _p(rank, _i64p), _p(out, _i64p)))
+        return out
 
     def C(self, alpha_max):
         out = np.empty(alpha_max + 1, dtype=np.int64)

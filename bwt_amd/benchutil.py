@@ -74,6 +74,9 @@ def phase_table(timers, steps):
     out = {}
     for k, v in sorted(timers.items(), key=lambda kv: -kv[1][0]):
         ms, work, calls = v
+        if "=" in k:  # launch counters (which kernel variant ran), not phases
+            out[k] = {"calls": calls}
+            continue
         row = {"ms_per_step": round(ms / steps, 3), "calls": calls}
         if ms > 0 and work > 0:
             if k in TRANSACTION_TIMERS:

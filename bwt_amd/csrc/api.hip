@@ -467,6 +467,47 @@ int bwt_hip_block_LF(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uin
   API_END
 }
 
+int bwt_hip_block_ibwt(bwt_hip_ctx *ctx, bwt_hip_block *blk_, uint8_t *I_host, int64_t *mismatches) {
+  API_BEGIN
+  need(ctx && blk_, "ctx, blk");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  HIP_CHECK(hipSetDevice(c.device));
+  Block &blk = *as_block(blk_);
+  DBuf<u8> out;
+  if (I_host) out = DBuf<u8>(c, (size_t)blk.len());
+  i64 bad = 0;
+  inverse_block(c, blk, out.get(), mismatches ? &bad : nullptr);
+  if (mismatches) *mismatches = bad;
+  if (I_host) {
+    HIP_CHECK(hipMemcpyAsync(I_host, out.get(), (size_t)blk.len(), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+  }
+  API_END
+}
+
+int bwt_hip_block_sa(bwt_hip_ctx *ctx, bwt_hip_block *blk_, int64_t nq, const int64_t *rank, int64_t *pos_out) {
+  API_BEGIN
+  need(ctx && blk_ && nq >= 0 && (nq == 0 || (rank && pos_out)), "ctx, blk, nq >= 0, rank, pos_out");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  Block &blk = *as_block(blk_);
+  if (nq > 0) {
+    std::vector<u32> h((size_t)nq);
+    for (i64 k = 0; k < nq; k++) {
+      if (rank[k] < blk.a || rank[k] >= blk.b) fail(BWT_HIP_EINVAL, "query %ld: rank %ld outside [a,b)", (long)k, (long)rank[k]);
+      h[(size_t)k] = (u32)(rank[k] - blk.a);
+    }
+    DBuf<u32> dq(c, (size_t)nq), dout(c, (size_t)nq);
+    HIP_CHECK(hipMemcpyAsync(dq.get(), h.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c.stream));
+    sa_batch(c, blk, dq.get(), dout.get(), (size_t)nq);
+    HIP_CHECK(hipMemcpyAsync(h.data(), dout.get(), (size_t)nq * 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    for (i64 k = 0; k < nq; k++) pos_out[k] = (i64)h[(size_t)k];
+  }
+  API_END
+}
+
 int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l_, bwt_hip_block *r_, int64_t seg, int64_t *gap_out,
                 int64_t *g_out) {
   API_BEGIN

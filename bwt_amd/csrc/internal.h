@@ -277,6 +277,9 @@ Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns);
 void count_alphabets(Ctx &c, Block &blk);
 void build_wavelet(Ctx &c, Block &blk);
 void rank_batch(Ctx &c, Block &blk, const u8 *d_sym, const u32 *d_pos, u32 *d_out, size_t nq, bool lf);
+// inverse.hip: the block decoded back to text (ibwt), SA[r] for a batch of ranks (sa)
+void inverse_block(Ctx &c, Block &blk, u8 *out_dev, i64 *mismatches);
+void sa_batch(Ctx &c, Block &blk, const u32 *d_rank, u32 *d_out, size_t nq);
 // gap.hip: the inclusive prefix sums S[i] = #{j : g_j <= i}, i in [0, m], of
 // the gap array, plus g_j at the right block's sample positions
 struct GapResult {

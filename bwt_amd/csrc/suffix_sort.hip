@@ -952,6 +952,12 @@ static void launch_bucket_emit(Ctx &c, const LeafEmit<PackedView> &em, u32 max_b
   const u32 items = ceil_div(max_bucket ? max_bucket : 1, BK_THREADS);
   if (items > (u32)BK_ITEMS) fail(BWT_HIP_EINTERNAL, "bucket of %u elements", max_bucket);
   const dim3 grid(BK_BUCKETS), block(BK_THREADS);
+  if (c.timing_level >= 2) {  // a counter, not a timer: which instantiation the bucket sizes selected
+    const u32 variant = items <= 4 ? 4 : (items <= 6 ? 6 : (items <= 8 ? 8 : (u32)BK_ITEMS));
+    char name[64];
+    snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s", variant, SLACK ? ",slack" : "");
+    c.timers[(size_t)c.timer_index(name)].launches++;
+  }
   if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
   else if (items <= 6) hipLaunchKernelGGL((k_bucket_emit<SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
   else if (items <= 8) hipLaunchKernelGGL((k_bucket_emit<SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);

@@ -146,6 +146,16 @@ int bwt_hip_block_rank(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const u
 int bwt_hip_block_LF(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const uint8_t *sym, const int64_t *rank,
                      int64_t *out);
 
+/* bwt::ibwt (include/bwt.h:276-285; the round trip of src/pmbwt.cc:64-81): decodes the block back to
+   T[a:b).  The serial LF walk of the reference is cut at the block's samples, one device thread per
+   sample.  I_host (b-a bytes) may be null; *mismatches (may be null) = positions where the decoded text
+   differs from the context's text, plus samples whose rank the walk does not reach: 0 iff L and the sample
+   set describe T[a:b). */
+int bwt_hip_block_ibwt(bwt_hip_ctx *ctx, bwt_hip_block *blk, uint8_t *I_host, int64_t *mismatches);
+
+/* Batched bwt::sa (include/bwt.h:456-481): pos_out[k] = text position of the suffix of absolute rank rank[k]. */
+int bwt_hip_block_sa(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const int64_t *rank, int64_t *pos_out);
+
 /* build_gap (include/bwt.h:730-787) without consuming the blocks:
    gap_out[i - l.a] = gap.get(i) for i in [l.a, l.b] (l.b-l.a+1 entries);
    g_out[j - r.a] = insertion point of T[j:] among l's suffixes, absolute

@@ -1,0 +1,143 @@
+"""GPU parity at the sizes the benchmark runs: the leaf sort's bucket route as it is taken unforced (windows of
+1e8 suffixes and more, buckets of thousands of suffixes, every instantiation of k_bucket_emit), the packed and
+the pairs layout, config 2 (n = 1e9, 2 leaves) and config 3 (n = 3.1e9, 8 leaves) of bwt::pmbwt
+(reference include/bwt.h:867-883).
+
+Pinned to the reference itself where the serial reference finishes in minutes (tests/golden/golden_large.json:
+whole builds at 1e7 and 1e8, single leaves of 3.6e8 to 5.6e8 suffixes); beyond that by size-independent
+properties -- the same L from the bucket route and from the plain radix passes, the same L from different
+leaf sizes, L a permutation of T, L[rank] = T[pos-1] at every sample -- and by decoding L back to the text
+on the device."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden_util import check_block, h8
+from tests.gpu_util import ctx  # noqa: F401
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "golden_large.json")) as f:
+    GL = json.load(f)
+
+
+def launches(ctx, name):
+    return ctx.timers().get(name, (0, 0, 0))[2]
+
+
+def variants(ctx):
+    return sorted(k for k, v in ctx.timers().items() if k.startswith("leaf:bucket_emit_items=") and v[2] > 0)
+
+
+@pytest.fixture()
+def timed(ctx):
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    yield ctx
+    ctx.set_timing(0)
+    ctx.trim()
+
+
+@pytest.mark.parametrize("rec", GL["pipeline"], ids=lambda r: r["name"])
+def test_golden_large_pipeline(timed, rec):
+    """Whole builds against records of the reference: n = 1e7 (16 leaves; DNA and bytes), n = 1e8 with 1, 2 and
+    16 leaves.  The single leaf of 1e8 suffixes takes the bucket route by itself."""
+    ctx = timed
+    t = rec["text"]
+    ctx.gen_text(t["n"], t["seed"], t["sigma"])
+    blk = ctx.pmbwt(rec["bwt_rec_threshold"], rec["ssa_n_samples"], rec["opts"].get("seg", 0))
+    check_block(blk, blk.L, rec, 0, t["n"])
+    if rec["name"].endswith("n1e8_1leaf"):
+        assert launches(ctx, "leaf:k_bucket_emit") == 1 and variants(ctx) == ["leaf:bucket_emit_items=4"]
+    blk.free()
+
+
+@pytest.mark.parametrize("rec", GL.get("leaf", []), ids=lambda r: r["name"])
+def test_golden_large_leaf(timed, rec):
+    """bwt_leaf on windows whose buckets hold 5500 to 8600 suffixes: the 6-, 8- and 9-element instantiations of
+    k_bucket_emit, with and without window slack, against the reference's leaf (L, special ranks, samples)."""
+    ctx = timed
+    t = rec["text"]
+    ctx.gen_text(t["n"], t["seed"], t["sigma"])
+    blk = ctx.leaf(rec["a"], rec["b"], rec["ssa_n_samples"])
+    check_block(blk, blk.L, rec, 0, rec["b"] - rec["a"])
+    want = {"leaf_s4_whole_5.6e8": "leaf:bucket_emit_items=9", "leaf_s4_first_5e8_of_5.01e8": "leaf:bucket_emit_items=8,slack",
+            "leaf_s4_mid_3.6e8": "leaf:bucket_emit_items=6,slack"}[rec["name"]]
+    assert launches(ctx, "leaf:k_bucket_emit") == 1 and variants(ctx) == [want]
+    blk.free()
+
+
+def _plain_route_context(n):
+    """A second context on the same GPU whose leaf sorts never take the bucket route."""
+    import bwt_amd
+    old = os.environ.get("BWT_HIP_BUCKET_MIN_N")
+    os.environ["BWT_HIP_BUCKET_MIN_N"] = str(4 * n)
+    try:
+        return bwt_amd.Context(0)
+    finally:
+        if old is None:
+            del os.environ["BWT_HIP_BUCKET_MIN_N"]
+        else:
+            os.environ["BWT_HIP_BUCKET_MIN_N"] = old
+
+
+def _build(c, n, leaves, ns):
+    blk = c.pmbwt(-(-n // leaves), ns)
+    L = blk.L
+    r, p = blk.samples()
+    info = (blk.s_rank, blk.e_rank, blk.e_char)
+    return blk, L, r, p, info
+
+
+def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves):
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    ctx.gen_text(n, 42, 4)
+    blk, L, r, p, info = _build(ctx, n, leaves, ns)
+    got = variants(ctx)
+    ctx.set_timing(0)
+    assert launches(ctx, "leaf:k_bucket_emit") == leaves and got == expect_variants, got
+    # decoded on the device, L gives the text back (src/pmbwt.cc:64-81 check_result)
+    assert blk.ibwt_mismatches() == 0
+    blk.free()
+    T = ctx.get_text()
+    # L is a permutation of T with the terminator at s_rank; every sample (rank, pos) has L[rank] = T[pos-1]
+    assert (np.bincount(L, minlength=256) == np.bincount(T, minlength=256)).all()
+    assert L[info[0]] == 0 and info[1] == 0 and info[2] == 0
+    assert p[0] == 0 and p[-1] == n - 1 and (np.diff(p) > 0).all()
+    assert (L[r] == T[p - 1]).all()
+    del T
+    fnv = h8(L)
+    # the same tree with the plain radix passes instead of the bucket route: same L, same samples
+    ctx.trim()
+    plain = _plain_route_context(n)
+    try:
+        plain.set_timing(2)
+        plain.gen_text(n, 42, 4)
+        b2, L2, r2, p2, info2 = _build(plain, n, leaves, ns)
+        assert launches(plain, "leaf:k_bucket_emit") == 0
+        assert info2 == info and (r2 == r).all() and (p2 == p).all()
+        assert (L2 == L).all()
+        b2.free()
+        del L2
+        # another leaf size: L does not depend on it (samples do)
+        b3 = plain.pmbwt(-(-n // other_leaves), ns)
+        assert h8(b3.L) == fnv
+        b3.free()
+    finally:
+        plain.close()
+    return fnv
+
+
+def test_config2_n1e9_two_leaves(ctx):
+    """Config 2 as bench.py --n 1000000000 --leaves 2 runs it: both leaves on the bucket route (8 elements per
+    thread; the left one with window slack)."""
+    _full_size(ctx, 10 ** 9, 2, 12500000, ["leaf:bucket_emit_items=8", "leaf:bucket_emit_items=8,slack"], 4)
+
+
+def test_config3_n3_1e9_eight_leaves(ctx):
+    """Config 3 on one GPU as bench.py runs it by default: 8 leaves of 3.875e8 suffixes, 7 merges."""
+    _full_size(ctx, 3100000000, 8, 19375000, ["leaf:bucket_emit_items=8", "leaf:bucket_emit_items=8,slack"], 4)
+    ctx.trim()
