@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path bwt::pmbwt on MI355X.
 
-One step = one whole BWT build (leaf suffix sorts + gap-array merges) of a synthetic DNA text that is
-already resident in HBM; the result L stays in HBM.  Metric: Mbase/s = (n-1) / seconds per build.
+One step = one whole BWT build (leaf suffix sorts + gap-array merges) of ONE synthetic DNA text.
+Metric: Mbase/s = (n-1) / seconds per build.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n N_CHARS] [--sigma S] [--leaves P]
 
-N = 1 runs the configuration the headline metric is quoted on for one GPU: random DNA, n = 1e9, two leaves
-of 5e8 and one gap-array merge.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the ranks share
-ONE text of 3.1e9 symbols: each builds the leaves of its part, and every merge of the tree runs on all GPUs of its
-subtree, exchanging chain heads, gap counts and block slices over RCCL (bwt_amd/multi_gpu.py, bwt_amd/dist_merge.py);
-that is strong scaling.
+Default workload, the same for every N: random DNA of n = 3.1e9 symbols (GRCh38-sized) cut into 8 leaves
+of 3.875e8 suffixes and merged by a tree of 7 gap-array merges.  On one GPU the whole tree runs there; on
+N GPUs (launched by torch.distributed.run, one rank per GPU) every rank builds 8/N leaves and each merge of
+the upper levels runs on all GPUs of its subtree (bwt_amd/dist_merge.py): strong scaling of one text.
+`--n 1000000000 --leaves 2` is the one-GPU configuration "leaf sort + single gap-array merge".
+
+`value` is measured with the text already in HBM and the result left in HBM.  The same line also carries
+`host_to_host`: text in (page-locked) host memory before, L and the samples in host memory after, the
+transfers inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+METRIC = "BWT build Mbase/s end-to-end, 3.1 Gbp DNA, at 1/2/4/8 MI355X"
+DEFAULT_N = 3100000000
+DEFAULT_LEAVES = 8
 
 
 class stdout_to_stderr:
@@ -63,24 +71,90 @@ def cpu_baseline(budget_n):
                       % (n, what, dt)}
 
 
+def default_samples(n, leaves):
+    """ssa_n_samples as the reference's set_defaults derives it at mem_budget 4 for this recursion depth
+    (include/opts.h:286-289)."""
+    return max(1000, int(0.4 * n / (1 + max(1, leaves.bit_length() - 1)) / 16))
+
+
+def workload_text(n, sigma, leaves, world):
+    merges = leaves - 1
+    if world == 1:
+        return "random DNA n=%d on one MI355X: %d leaf suffix sorts + %d gap-array merge(s)" % (n, leaves, merges)
+    return ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its subtree "
+            "(RCCL point-to-point + all-to-all)" % (n, leaves, world))
+
+
+def timed_builds(ctx, th, ns, seg, steps):
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        blk = ctx.pmbwt(th, ns, seg)
+        ctx.sync()
+        blk.free()
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def host_to_host(ctx, n, th, ns, seg, steps):
+    """(n-1)/time of: upload T from host memory, build, download L and the samples.  Page-locked buffers on
+    the host side; every byte crosses the link inside the timed region."""
+    import numpy as np
+    import bwt_amd
+    Th, Lh = bwt_amd.HostBuffer(n), bwt_amd.HostBuffer(n)
+    ctx.read_text(Th.a)  # the text the resident runs used, now on the host
+    n_samp = min(n, ns)
+    Sr, Sp = bwt_amd.HostBuffer(8 * n_samp), bwt_amd.HostBuffer(8 * n_samp)
+    sr, sp = Sr.a.view(np.int64), Sp.a.view(np.int64)
+    parts = {"upload_ms": 0.0, "build_ms": 0.0, "download_ms": 0.0}
+
+    def once(record):
+        t0 = time.perf_counter()
+        ctx.set_text(Th.a)
+        t1 = time.perf_counter()
+        blk = ctx.pmbwt(th, ns, seg)
+        ctx.sync()
+        t2 = time.perf_counter()
+        blk.read_L(Lh.a)
+        k = blk.read_samples(sr, sp)
+        t3 = time.perf_counter()
+        blk.free()
+        if record:
+            parts["upload_ms"] += (t1 - t0) * 1e3
+            parts["build_ms"] += (t2 - t1) * 1e3
+            parts["download_ms"] += (t3 - t2) * 1e3
+        return t3 - t0, k
+
+    once(False)
+    total = 0.0
+    for _ in range(steps):
+        dt, k = once(True)
+        total += dt
+    dt = total / steps
+    ok = bool(Lh.a[0] != 0 or n < 3) and int(sp[k - 1]) == n - 1
+    out = {"value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "what": "T in page-locked host memory -> bwt_hip_set_text -> build -> L and %d samples in page-locked host memory" % k,
+           "sanity": ok}
+    out.update({k_: round(v / steps, 3) for k_, v in parts.items()})
+    for b in (Th, Lh, Sr, Sp):
+        b.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--text_len", "--n", dest="n", type=int, default=None, help="text length (default 1e9 on one GPU, 3.1e9 on several)")
+    ap.add_argument("--text_len", "--n", dest="n", type=int, default=DEFAULT_N, help="text length (default 3.1e9)")
     ap.add_argument("--sigma", type=int, default=4)
-    ap.add_argument("--leaves", type=int, default=None, help="leaves (power of two; default 2 on one GPU, one per GPU on several)")
+    ap.add_argument("--leaves", type=int, default=DEFAULT_LEAVES,
+                    help="leaves of the whole tree (a power of two, at least one per GPU; default 8)")
     ap.add_argument("--ssa_n_samples", type=int, default=0)
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--cpu_n", type=int, default=3 * 10 ** 7, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-timers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-to-host leg and the other tree shapes")
     args = ap.parse_args()
-    args.n_given, args.leaves_given = args.n is not None, args.leaves is not None
-    if args.n is None:
-        args.n = 10 ** 9
-    if args.leaves is None:
-        args.leaves = 2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,31 +164,26 @@ def main():
             print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus),
                   file=sys.stderr)
             sys.exit(2)
+    if args.leaves < 1 or args.leaves & (args.leaves - 1) or args.leaves % world:
+        print("--leaves %d: must be a power of two and a multiple of the %d GPUs" % (args.leaves, world), file=sys.stderr)
+        sys.exit(2)
 
     import bwt_amd
     if world > 1 or os.environ.get("BWT_BENCH_FORCE_DIST"):  # the env switch rehearses the N > 1 leg on one GPU
         from bwt_amd import multi_gpu
-        return multi_gpu.bench_main(args, rank, local_rank, world)
+        return multi_gpu.bench_main(args, rank, local_rank, world, METRIC, cpu_baseline)
 
     n = args.n
     ctx = bwt_amd.Context(0)
     ctx.gen_text(n, 42, args.sigma)
-    # the reference derives ssa_n_samples from mem_budget (include/opts.h:286-289); at mem_budget 4 and
-    # two levels of recursion that is n/5/... ; use its default formula's value for 2 leaves: 0.4n/(1+1)/16
-    ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, args.leaves.bit_length() - 1)) / 16))
+    ns = args.ssa_n_samples or default_samples(n, args.leaves)
     th = -(-n // args.leaves)
     for _ in range(args.warmup):
         ctx.pmbwt(th, ns, args.seg).free()
     ctx.sync()
     ctx.set_timing(0 if args.no_timers else 2)
     ctx.reset_timers()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        blk = ctx.pmbwt(th, ns, args.seg)
-        ctx.sync()
-        blk.free()
-    ctx.sync()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = timed_builds(ctx, th, ns, args.seg, args.steps)
     timers = ctx.timers()
     ctx.set_timing(0)
     mem = ctx.mem_stats()
@@ -123,18 +192,30 @@ def main():
     roof = roofline(timers, ROOT, {"n": n, "leaves": args.leaves})
     phases = phase_table(timers, args.steps)
     out = {
-        "metric": "BWT build Mbase/s end-to-end", "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
+        "metric": METRIC, "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on the device" % args.sigma,
-        "config": {"workload": "random DNA n=%d on one MI355X: %d leaf suffix sorts + %d gap-array merge(s)"
-                               % (n, args.leaves, args.leaves - 1),
+        "value_definition": "text resident in HBM before the timed region, L and samples left in HBM; host_to_host has the transfers inside",
+        "config": {"workload": workload_text(n, args.sigma, args.leaves, 1),
                    "n": n, "sigma": args.sigma, "leaves": args.leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                    "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True},
         "roofline": roof,
         "phases": phases,
         "device_mem_peak_gb": round(mem["peak"] / 1e9, 2),
     }
+    if not args.no_extras:
+        out["host_to_host"] = host_to_host(ctx, n, th, ns, args.seg, min(args.steps, 3))
+        # the same text as fewer, larger leaves (one step each after one untimed build)
+        other = {}
+        for leaves in (2, 1):
+            if leaves >= args.leaves:
+                continue
+            th2, ns2 = -(-n // leaves), default_samples(n, leaves)
+            ctx.pmbwt(th2, ns2, args.seg).free()
+            d2 = timed_builds(ctx, th2, ns2, args.seg, 1)
+            other["leaves=%d" % leaves] = {"ms_per_step": round(d2 * 1e3, 3), "Mbase_per_s": round((n - 1) / d2 / 1e6, 2)}
+        out["other_trees"] = other
     ctx.close()
     if args.cpu_n:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)

@@ -93,6 +93,10 @@ def lib():
     L.bwt_hip_destroy.restype = None
     L.bwt_hip_block_free.argtypes = [vp, vp]
     L.bwt_hip_block_free.restype = None
+    L.bwt_hip_host_alloc.argtypes = [i64, C.POINTER(vp)]
+    L.bwt_hip_host_alloc.restype = i32
+    L.bwt_hip_host_free.argtypes = [vp]
+    L.bwt_hip_host_free.restype = None
     L.bwt_hip_stream.argtypes = [vp]
     L.bwt_hip_stream.restype = vp
     _lib = L
@@ -106,6 +110,27 @@ def _chk(rc):
 
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+class HostBuffer:
+    """Page-locked host memory as a numpy uint8 array (`.a`); freed by close() or with the object."""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        _chk(lib().bwt_hip_host_alloc(nbytes, C.byref(self._p)))
+        self.a = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p.value))
+
+    def close(self):
+        if self._p:
+            self.a = None
+            lib().bwt_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def dist_bounds(m, parts):
@@ -152,6 +177,11 @@ class Context:
         T = np.empty(self.n, dtype=np.uint8)
         _chk(lib().bwt_hip_get_text(self._h, _p(T, _u8p)))
         return T
+
+    def read_text(self, out):
+        """The context's text into a caller's uint8 array (for example page-locked memory of HostBuffer)."""
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and len(out) >= self.n
+        _chk(lib().bwt_hip_get_text(self._h, _p(out, _u8p)))
 
     # ---- pipeline ---------------------------------------------------------
     def _blk(self, h):
@@ -315,6 +345,11 @@ class Block:
         _chk(lib().bwt_hip_block_get_L(self.ctx._h, self._h, _p(out, _u8p)))
         return out
 
+    def read_L(self, out):
+        """L[a:b) into a caller's uint8 array (for example page-locked memory of HostBuffer)."""
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and len(out) >= self.b - self.a
+        _chk(lib().bwt_hip_block_get_L(self.ctx._h, self._h, _p(out, _u8p)))
+
     @property
     def L_device(self):
         p = C.c_void_p()
@@ -331,6 +366,13 @@ class Block:
         p = np.empty(self.n_samples, dtype=np.int64)
         _chk(lib().bwt_hip_block_get_samples(self.ctx._h, self._h, _p(r, _i64p), _p(p, _i64p), self.n_samples))
         return r, p
+
+    def read_samples(self, rank_out, pos_out):
+        """The samples into a caller's int64 arrays; returns how many were written."""
+        k = min(self.n_samples, len(rank_out), len(pos_out))
+        assert rank_out.dtype == np.int64 and pos_out.dtype == np.int64
+        _chk(lib().bwt_hip_block_get_samples(self.ctx._h, self._h, _p(rank_out, _i64p), _p(pos_out, _i64p), k))
+        return k
 
     def init_extra(self):
         _chk(lib().bwt_hip_block_init_extra(self.ctx._h, self._h))

@@ -52,12 +52,13 @@ def roofline(timers, repo_root=None, workload=None):
     # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
     # runs, corrected per kernel as the file says); only valid for the workload they were taken on
     if repo_root and workload:
-        tfile = os.path.join(repo_root, "profiles", "r1_traffic.json")
-        if os.path.exists(tfile):
+        import glob
+        for tfile in sorted(glob.glob(os.path.join(repo_root, "profiles", "r*_traffic*.json")), reverse=True):
             t = json.load(open(tfile))
             if t.get("workload") == workload and name in t.get("kernels", {}):
                 roof["traffic"] = t["kernels"][name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_traffic.json"
+                roof["traffic_source"] = "profiles/" + os.path.basename(tfile)
+                break
     if kind == "sectors":
         roof["random_read_ceiling"] = {"reads_per_s": RANDOM_READS_PER_S, "achieved_reads_per_s": round(work / (ms * 1e-3), 1),
                                        "frac": round(work / (ms * 1e-3) / RANDOM_READS_PER_S, 4),

@@ -86,6 +86,17 @@ void bwt_hip_destroy(bwt_hip_ctx *ctx) {
   delete ctx;
 }
 
+int bwt_hip_host_alloc(int64_t bytes, void **out) {
+  API_BEGIN
+  need(out != nullptr && bytes > 0, "out, bytes > 0");
+  HIP_CHECK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  API_END
+}
+
+void bwt_hip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 static void drop_text(Ctx &c) {
   if (c.T_owned) c.release(c.T_owned);
   c.T_owned = nullptr;
@@ -378,16 +389,18 @@ int bwt_hip_block_get_samples(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, int64
   API_BEGIN
   need(ctx && blk_ && rank_out && pos_out, "ctx, blk, rank_out, pos_out");
   const Block *blk = as_block(blk_);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
   i64 k = blk->n_samp < cap ? blk->n_samp : cap;
   if (k > 0) {
-    std::vector<u32> hr((size_t)k), hp((size_t)k);
-    HIP_CHECK(hipMemcpyAsync(hr.data(), blk->samp_rank.get(), (size_t)k * 4, hipMemcpyDeviceToHost, ctx->c.stream));
-    HIP_CHECK(hipMemcpyAsync(hp.data(), blk->samp_pos.get(), (size_t)k * 4, hipMemcpyDeviceToHost, ctx->c.stream));
-    ctx->c.sync();
-    for (i64 i = 0; i < k; i++) {
-      rank_out[i] = blk->a + (i64)hr[(size_t)i];
-      pos_out[i] = (i64)hp[(size_t)i];
-    }
+    // widened to the reference's idx_t on the device, then one copy per array straight into the caller's memory
+    DBuf<i64> wr(c, (size_t)k), wp(c, (size_t)k);
+    hipLaunchKernelGGL(k_widen_samples, dim3(ceil_div(k, 256)), dim3(256), 0, c.stream, blk->samp_rank.get(),
+                       blk->samp_pos.get(), (u32)k, blk->a, wr.get(), wp.get());
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(rank_out, wr.get(), (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(pos_out, wp.get(), (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
   }
   API_END
 }

@@ -165,6 +165,10 @@ struct Phase {
   hipEvent_t e0 = nullptr;
   Phase(Ctx &ctx, const char *name, double bytes = 0);
   ~Phase();
+  // more algorithmic work, for phases whose route (and with it their work) is known only afterwards
+  void add_work(double bytes) {
+    if (idx >= 0) c.timers[(size_t)idx].bytes += bytes;
+  }
 };
 
 // the same around ONE kernel launch, recorded only at timing_level >= 2

@@ -1151,8 +1151,14 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
     u64 *el[2] = {eb0.get(), eb1.get()};
     int cur;
     {
-      Phase ph(c, "leaf_radix_sort", (double)N * (passes * 24 - 15));
+      // Algorithmic bytes per window suffix: the text pass reads a symbol twice (tile histogram, scatter) and
+      // writes the 8-byte element plus the next pass's digit; the second pass reads that digit and moves the
+      // element (16); every further pass reads the element for its histogram (8) and moves it (16).  The
+      // bucket route stops after the second pass.
+      Phase ph(c, "leaf_radix_sort", 0);
       cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, &bs);
+      const int done = bs.pending ? 2 : passes;
+      ph.add_work((double)N * (done <= 1 ? 10 : 11 + 17 + (done - 2) * 24));
     }
     PackedView v{el[cur], nullptr, (u32)a, (u32)((1ull << kp.pbits) - 1), kp.pbits};
     return finish_window<PackedView>(c, a, b, e, N, K0, sym_mask, v, nullptr, el[cur], (u32 *)el[cur ^ 1], grp.get(), E,

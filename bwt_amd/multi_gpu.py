@@ -132,8 +132,9 @@ def pmbwt_tree(ops, rank, world, n, leaves_per_rank, dist, hdr_device="cpu", fre
     return blk
 
 
-def bench_main(args, rank, local_rank, world):
-    """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs."""
+def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
+    """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs.  --leaves is the leaf count of the
+    whole tree (the same tree as on one GPU), so every rank builds leaves / world of them."""
     # RCCL prints a version banner on standard output when its first communicator comes up.  This program's
     # standard output is one JSON line: descriptor 1 points at stderr from here on, the line goes out through
     # a copy of the original descriptor.
@@ -146,17 +147,11 @@ def bench_main(args, rank, local_rank, world):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist.init_process_group(backend="nccl", device_id=dev)
-    n = args.n if args.n_given else 3100000000
+    n = args.n
     ctx = bwt_amd.Context(local_rank)
     ctx.gen_text(n, 42, args.sigma)
-    if args.leaves_given:
-        lpr = max(1, args.leaves // 2)
-    else:
-        # One leaf per GPU, except where halving a GPU's share brings the leaves under 2^29 suffixes: there the
-        # 8-byte elements and the bucket route of the leaf sort beat one leaf of key + position pairs even with
-        # the local merge added (7.75e8 suffixes: about 26 ms against 32 ms).
-        share = n // world
-        lpr = 2 if (1 << 29) < share + share // 256 <= (1 << 30) else 1
+    assert args.leaves % world == 0 and args.leaves & (args.leaves - 1) == 0, "--leaves: a power of two, a multiple of the GPUs"
+    lpr = args.leaves // world
     total_leaves = world * lpr
     depth = total_leaves.bit_length() - 1
     ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
@@ -215,7 +210,7 @@ def bench_main(args, rank, local_rank, world):
         from bwt_amd.benchutil import phase_table, roofline
         th = leaf_threshold(n, total_leaves)
         out = {
-            "metric": "BWT build Mbase/s end-to-end", "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
+            "metric": metric, "value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
@@ -231,10 +226,14 @@ def bench_main(args, rank, local_rank, world):
             "roofline": roofline(timers), "cpu_baseline": None,
             "phases_rank0": phase_table(timers, args.steps),
         }
-        import ctypes
-        ctypes.CDLL(None).fflush(None)  # whatever C code still holds in its buffers goes to stderr first
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if last is not None:
         last.free()
     ctx.close()
     dist.destroy_process_group()
+    if rank == 0:
+        # after the process group is gone: the other ranks are not kept waiting in a collective meanwhile
+        if args.cpu_n:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # whatever C code still holds in its buffers goes to stderr first
+        os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -48,3 +48,30 @@ def test_phase_table_units():
     assert p["gap_chains"]["rate_unit"] == "Gtransactions/s" and p["merge_scatter"]["rate_unit"] == "GB/s"
     assert abs(p["gap_chains"]["ms_per_step"] - 10.5) < 1e-9
     assert list(p)[0] == "gap_chains"
+
+
+def test_no_phase_of_a_recorded_bench_line_exceeds_the_peak():
+    """Every bench line kept under profiles/ (and the driver's BENCH_r*.json of this round on) prices its phases
+    against the 8 TB/s peak: a fraction above 1 means the byte model is not what the kernels do."""
+    import glob
+    seen = 0
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r2_bench*.json")):
+        line = json.load(open(path))
+        line = line.get("parsed", line)
+        for name, row in (line.get("phases") or {}).items():
+            assert row.get("frac_of_peak", 0) <= 1.0, (path, name, row)
+            seen += 1
+        assert line["roofline"]["frac"] <= 1.0
+    assert seen > 0
+
+
+def test_bench_rejects_leaf_counts_that_do_not_fit_the_gpus():
+    import subprocess
+    import sys
+    for leaves in ("3", "0", "6"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--leaves", leaves], capture_output=True, text=True)
+        assert r.returncode == 2 and "power of two" in r.stderr
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--leaves", "2"], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 2 and "multiple of the 4 GPUs" in r.stderr

@@ -8,7 +8,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu_n 0 > $OUT/bench_under_rocprof.json 2> $OUT/kt.err || exit 1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu_n 0 --no-timers > $OUT/fetch.log 2>&1 || exit 2
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu_n 0 --no-timers > $OUT/write.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu_n 0 --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/kt.err || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu_n 0 --no-extras --no-timers > $OUT/fetch.log 2>&1 || exit 2
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu_n 0 --no-extras --no-timers > $OUT/write.log 2>&1 || exit 3
 python3 $R/tools/profile_summary.py $OUT $TAG
