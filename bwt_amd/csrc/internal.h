@@ -79,6 +79,10 @@ struct Ctx {
   // leaf windows of at least this many suffixes may take the bucket route of the leaf sort (two passes
   // on the top 16 key bits, the rest in LDS); below it the 65536 buckets are too small to pay
   u64 bucket_min_n = 100000000;  // measured crossover on random DNA: 7e7 suffixes 2.3 vs 1.9 ms, 1.4e8 suffixes 3.1 vs 3.6 ms
+  // tests and tuning: take the wide bucket route wherever the alphabet allows it (not only where the packed
+  // elements run out of position bits); bucket bits of that route (0 = by window length)
+  bool force_wide = false;
+  int wide_bbits = 0;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;
@@ -223,6 +227,10 @@ struct TextKeys {
   // pass's histogram reads one byte per element instead of eight.
   u8 *next_digits;
   int next_shift;
+  // WIDE elements, for windows whose positions need all 32 bits (K0 * w <= 36, symbols below 16):
+  //   element | key bits 63..32 | absolute text position, 32 bits |   side byte | key bits 31..28 | T[a+i-1], 4 bits |
+  // made by the text pass when set; the side bytes travel with their elements through the later passes.
+  int wide;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
@@ -236,12 +244,15 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
 struct BucketState {
   DBuf<u32> start;
   int begin_bit = 0;
+  int bbits = 16;      // a bucket = the elements that share their top bbits key bits
   u32 max_bucket = 0;  // elements of the largest bucket
   bool pending = false;
 };
 int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs);
 void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs);
-void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket);
+void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket, int bbits = 16);
+int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,
+                        BucketState *bs);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------

@@ -230,12 +230,15 @@ __device__ __forceinline__ u32 digit_of(K key, int shift, u32 mask) {
 // within the tile is then the old value of one LDS atomic add per key instead of the ballot ranking, which
 // costs a fifth of its vector instructions (gap histogram: 1.19 -> 1.08 ms per pass).  The leaf sort's first
 // pass gains as little and has to stay reverse-stable for the refinement rounds.
-template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE, bool ANY_ORDER = false>
+// SIDE: every key travels with one more byte (sd -> side_out), staged in side_s (RS_TILE bytes of LDS).
+template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE, bool ANY_ORDER = false, bool SIDE = false>
 __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
                                                 u32 *gbase, u32 *scan_s, K *__restrict__ kout,
                                                 u32 *__restrict__ vout, u32 tile_n, int shift, u32 mask,
                                                 const u32 *__restrict__ offs, u32 nblk, u32 tile, u32 stride,
-                                                u8 *__restrict__ next_digits = nullptr, int next_shift = 0) {
+                                                u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
+                                                const u8 *sd = nullptr, u8 *side_s = nullptr,
+                                                u8 *__restrict__ side_out = nullptr) {
   u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * 256;
   K *keys_s = reinterpret_cast<K *>(buf);
@@ -328,6 +331,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     if (FULL || wbase + r * 64 + lane < tile_n) {
       keys_s[rk[r]] = key[r];
       if (HAS_VALS) vals_s[rk[r]] = val[r];
+      if constexpr (SIDE) side_s[rk[r]] = sd[r];
     }
   }
   lds_barrier();
@@ -348,17 +352,23 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
         }
       }
       if (HAS_VALS) vout[dst] = vals_s[p];
+      if constexpr (SIDE) side_out[dst] = side_s[p];
     }
   }
 }
 
 // SPLIT: a 64-bit key lives as two 32-bit words `stride` words apart (all low words, then all high
 // words), so that a histogram pass reads only the half that holds its digit.
-template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false>
+// SIDE: 8-byte keys-only elements with a side byte each (the wide layout of the leaf sort, TextKeys::wide):
+// side_in[i] belongs to kin[i] and moves with it to side_out.  The text pass makes both from the text.
+template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false, bool SIDE = false>
 __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 : 8)
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
-                 u32 nblk, TextKeys tk, u32 stride) {
+                 u32 nblk, TextKeys tk, u32 stride, const u8 *__restrict__ side_in = nullptr,
+                 u8 *__restrict__ side_out = nullptr) {
+  static_assert(!SIDE || (sizeof(K) == 8 && !HAS_VALS && !SPLIT), "side bytes go with 8-byte keys-only elements");
+  u8 sd[RS_ITEMS];
   static_assert(!SPLIT || sizeof(K) == 8, "only 64-bit keys are split");
   // One LDS buffer, used twice: first the per-wave digit counters and the digit
   // starts, then (after every thread has turned its ranks into tile positions)
@@ -366,9 +376,10 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
   constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
   constexpr size_t TEXT_BYTES = TEXT ? (size_t)RS_TILE * 8 + TK_STAGE_WORDS * 4 : 0;  // key exchange + staged text
-  constexpr size_t BUF0 = STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES;
+  constexpr size_t BUF0 = (STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES) + (SIDE ? RS_TILE : 0);
   constexpr size_t BUF_BYTES = BUF0 > TEXT_BYTES ? BUF0 : TEXT_BYTES;
   __shared__ __align__(16) unsigned char buf[BUF_BYTES];
+  u8 *side_s = buf + STAGE_BYTES;  // SIDE: behind the staged keys (where the text pass kept its stretch of text before)
   __shared__ u32 gbase[256];
   __shared__ u32 scan_s[17];
 
@@ -408,6 +419,9 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
       if constexpr (HAS_VALS) {
         key[r] = (K)k;
         val[r] = pos0 + idx;
+      } else if constexpr (SIDE) {  // wide element: key bits 63..32 | absolute position; side: key bits 31..28 | preceding symbol
+        key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (u32)(pos0 + idx));
+        sd[r] = (u8)((((u32)k >> 28) << 4) | ((u32)k & 0xFu));
       } else {  // packed element: codes | preceding symbol | window index
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
       }
@@ -437,12 +451,14 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   } else {
     const K *kt = kin + tile0;      // uniform base + 32-bit lane offset
     const u32 *vt = vin + tile0;
+    const u8 *st = side_in + tile0;
     if (full) {
 #pragma unroll
       for (int r = 0; r < RS_ITEMS; r++) {
         u32 idx = wbase + r * 64 + lane;
         key[r] = kt[idx];
         if (HAS_VALS) val[r] = vt[idx];
+        if constexpr (SIDE) sd[r] = st[idx];
       }
     } else {
 #pragma unroll
@@ -451,15 +467,16 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
         bool valid = idx < tile_n;
         key[r] = valid ? kt[idx] : (K)0;
         if (HAS_VALS) val[r] = valid ? vt[idx] : 0u;
+        if constexpr (SIDE) sd[r] = valid ? st[idx] : (u8)0;
       }
     }
   }
   if (full)
-    rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
-                                              tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift);
+    rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
+                                              tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
   else
-    rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
-                                               nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift);
+    rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
+                                               nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -606,22 +623,22 @@ int leaf_sort_text_keys(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, u32 stride
 // four stable passes give, for half the trips through memory of the last two.  Needs every bucket to
 // fit a workgroup (BK_CAP elements): texts with a skewed distribution of 8-symbol words take the passes.
 // ----------------------------------------------------------------------------
-// start[k] = number of elements whose top 16 bits are below k, k = 0 .. 65536 (e is sorted on them)
-__global__ void k_bucket_bounds(const u64 *__restrict__ e, u32 n, u32 *__restrict__ start) {
+// start[k] = number of elements whose top `bbits` bits are below k, k = 0 .. 2^bbits (e is sorted on them)
+__global__ void k_bucket_bounds(const u64 *__restrict__ e, u32 n, u32 *__restrict__ start, u32 n_buckets, int bbits) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > BK_BUCKETS) return;
+  if (k > n_buckets) return;
   u32 lo = 0, hi = n;
   while (lo < hi) {
     const u32 mid = lo + (hi - lo) / 2;
-    if ((u32)(e[mid] >> 48) < k) lo = mid + 1;
+    if ((u32)(e[mid] >> (64 - bbits)) < k) lo = mid + 1;
     else hi = mid;
   }
   start[k] = lo;
 }
 
-__global__ void k_bucket_max(const u32 *__restrict__ start, u32 *__restrict__ out) {
+__global__ void k_bucket_max(const u32 *__restrict__ start, u32 *__restrict__ out, u32 n_buckets) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 v = k < BK_BUCKETS ? start[k + 1] - start[k] : 0u;
+  u32 v = k < n_buckets ? start[k + 1] - start[k] : 0u;
   v = wave_reduce_max(v);
   if (lane_id() == 0) atomicMax(out, v);
 }
@@ -666,7 +683,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_sort(u64 *__restrict__ e,
 // per_bucket[k] += the sampled text positions whose key, as the first radix pass builds it (TextKeys), has top
 // 16 bits k.  Samples: `count` positions from `first` on, in runs of 16 consecutive positions that start
 // `stride` apart (stride 16: every position).  One position per thread.
-__global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride, u32 *__restrict__ per_bucket) {
+__global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride, u32 *__restrict__ per_bucket, int bbits) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const u64 p = first + (t >> 4) * stride + (t & 15);
@@ -676,13 +693,13 @@ __global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride
     const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
     sf = (sf << tk.w) | (ch ? ch - ms : 0u);
   }
-  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> 48)], 1u);
+  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> (64 - bbits))], 1u);
 }
 
-void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket) {
+void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket, int bbits) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_bucket_histogram, dim3(ceil_div(count, 256)), dim3(256), 0, c.stream, tk, first, count, stride,
-                     per_bucket);
+                     per_bucket, bbits);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -695,38 +712,109 @@ __global__ void k_max_u32(const u32 *__restrict__ v, u32 n, u32 *__restrict__ ou
 // A sample of the window (16 positions out of every 4096) says whether some bucket will be far too large
 // for a workgroup (twice its capacity: sampling noise must not turn an even text away); the two passes on
 // the top 16 bits are then not worth trying.
-static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n) {
+static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n, int bbits = 16, u32 cap = BK_CAP) {
   constexpr u64 STRIDE = 256;  // one position in 256
+  const u32 n_buckets = 1u << bbits;
   const u64 count = n / (16 * STRIDE) * 16;
-  if (count < 4 * BK_BUCKETS) return true;  // too few samples to say anything
+  if (count < 4 * (u64)n_buckets) return true;  // too few samples to say anything
   KernelTimer kt(c, "leaf:k_bucket_histogram", (double)count * 8);
-  DBuf<u32> hist(c, BK_BUCKETS);
+  DBuf<u32> hist(c, n_buckets);
   u32 *d_max = c.d_scalars + 12;
-  HIP_CHECK(hipMemsetAsync(hist.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
+  HIP_CHECK(hipMemsetAsync(hist.get(), 0, n_buckets * sizeof(u32), c.stream));
   HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
-  bucket_histogram(c, tk, tk.a, count, 16 * STRIDE, hist.get());
-  hipLaunchKernelGGL(k_max_u32, dim3(BK_BUCKETS / 256), dim3(256), 0, c.stream, hist.get(), BK_BUCKETS, d_max);
+  bucket_histogram(c, tk, tk.a, count, 16 * STRIDE, hist.get(), bbits);
+  hipLaunchKernelGGL(k_max_u32, dim3(n_buckets / 256), dim3(256), 0, c.stream, hist.get(), n_buckets, d_max);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();
-  return (u64)c.h_scalars[0] * STRIDE <= (u64)BK_CAP * 2;
+  return (u64)c.h_scalars[0] * STRIDE <= (u64)cap * 2;
 }
 
-// Bucket bounds of e (already sorted on its top 16 bits).  False if some bucket does not fit a workgroup.
-static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start, u32 *max_bucket) {
-  start = DBuf<u32>(c, BK_BUCKETS + 1);
+// Bucket bounds of e (already sorted on its top bbits bits).  False if some bucket holds more than cap elements.
+static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start, u32 *max_bucket, int bbits = 16, u32 cap = BK_CAP) {
+  const u32 n_buckets = 1u << bbits;
+  start = DBuf<u32>(c, (size_t)n_buckets + 1);
   u32 *d_max = c.d_scalars + 12;
   {
-    KernelTimer kt(c, "leaf:k_bucket_bounds", (double)BK_BUCKETS * 8 * 29);
+    KernelTimer kt(c, "leaf:k_bucket_bounds", (double)n_buckets * 8 * 29);
     HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(BK_BUCKETS / 256 + 1), dim3(256), 0, c.stream, e, (u32)n, start.get());
-    hipLaunchKernelGGL(k_bucket_max, dim3(BK_BUCKETS / 256), dim3(256), 0, c.stream, start.get(), d_max);
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, e, (u32)n, start.get(), n_buckets, bbits);
+    hipLaunchKernelGGL(k_bucket_max, dim3(n_buckets / 256), dim3(256), 0, c.stream, start.get(), d_max, n_buckets);
     HIP_CHECK(hipGetLastError());
   }
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();
   *max_bucket = c.h_scalars[0];
-  return c.h_scalars[0] <= (u32)BK_CAP;
+  return c.h_scalars[0] <= cap;
+}
+
+// Round 0 with WIDE elements, for windows whose positions need all 32 bits (TextKeys::wide): radix passes on
+// the top bbits key bits only (16 < bbits <= 24: three passes, the first one -- from the text, on the
+// lowest of those bits -- reverse-stable as always), then the bucket bounds.  The caller finishes the
+// buckets from LDS (k_bucket_emit).  elems[b] / sides[b]: the two element and side-byte buffers; returns the
+// one that holds the result, or -1 if some bucket holds more than `cap` elements (nothing usable then).
+int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,
+                        BucketState *bs) {
+  if (bbits <= 16 || bbits > 24 || !text.wide || text.K0 * text.w > 36 || n >= (1ull << 32))
+    fail(BWT_HIP_EINTERNAL, "leaf sort: bad wide layout (bbits %d, K0 %d, w %d, n %zu)", bbits, text.K0, text.w, n);
+  if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
+  const u32 nblk = ceil_div(n, RS_TILE);
+  DBuf<u32> counts(c, (size_t)256 * nblk);
+  DBuf<u8> digits(c, n);
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  TextKeys first = text;
+  first.next_digits = digits.get();
+  first.next_shift = 48;
+  TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
+  if (count_keys.K0 * count_keys.w > 32) count_keys.K0 = 32 / count_keys.w;
+  int cur = 0;
+  const int shifts[3] = {64 - bbits, 48, 56};
+  for (int p = 0; p < 3; p++) {
+    const int shift = shifts[p];
+    const u32 mask = p == 0 ? (1u << (bbits - 16)) - 1u : 255u;
+    if (p == 0) {
+      {
+        KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
+        hipLaunchKernelGGL((k_rs_hist<u64, 0, true>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n,
+                           shift, mask, counts.get(), nblk, count_keys);
+        HIP_CHECK(hipGetLastError());
+      }
+      scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+      KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 11);
+      hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, false, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                         (const u64 *)nullptr, (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask,
+                         counts.get(), nblk, first, 0u, (const u8 *)nullptr, sides[cur ^ 1]);
+      HIP_CHECK(hipGetLastError());
+    } else {
+      if (p == 1) {
+        KernelTimer kt(c, "leaf:k_rs_hist_bytes", (double)n);
+        hipLaunchKernelGGL(k_rs_hist_bytes, dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u8 *)digits.get(), n,
+                           counts.get(), nblk);
+        HIP_CHECK(hipGetLastError());
+      } else {
+        KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
+        hipLaunchKernelGGL((k_rs_hist<u64, 0, false>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, elems[cur], n, shift, mask,
+                           counts.get(), nblk, none);
+        HIP_CHECK(hipGetLastError());
+      }
+      scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+      KernelTimer kt(c, "leaf:k_rs_scatter_u64_side", (double)n * 18);
+      hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, false, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                         elems[cur], (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(), nblk,
+                         none, 0u, (const u8 *)sides[cur], sides[cur ^ 1]);
+      HIP_CHECK(hipGetLastError());
+    }
+    cur ^= 1;
+  }
+  if (!bucket_bounds(c, elems[cur], n, bs->start, &bs->max_bucket, bbits, cap)) {
+    bs->start = DBuf<u32>();
+    return -1;
+  }
+  bs->begin_bit = 64 - bbits - 16;
+  bs->bbits = bbits;
+  bs->pending = true;
+  return cur;
 }
 
 // sorts every bucket of e on bits begin_bit..47, in place
@@ -752,6 +840,7 @@ int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const 
     BucketState local;
     BucketState &st = bs ? *bs : local;
     if (bucket_bounds(c, elems[cur], n, st.start, &st.max_bucket)) {
+      st.bbits = 16;
       st.begin_bit = begin_bit;
       st.pending = true;
       if (!bs) bucket_sort_in_place(c, elems[cur], n, st);

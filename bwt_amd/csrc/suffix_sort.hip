@@ -91,6 +91,11 @@ struct PackedView {
   const u32 *sa;   // null, or the positions once refinement rounds have taken them over
   u32 a, posmask;
   int pbits;
+  static constexpr bool WIDE = false;
+  // what the bucket kernel needs of an element (sd: its side byte, none in this layout)
+  __device__ __forceinline__ u32 bucket_key(u64 x, u32) const { return (u32)(x >> 32) & 0xFFFFu; }  // the 16 key bits below the bucket's
+  __device__ __forceinline__ u32 elem_pos(u64 x) const { return a + ((u32)x & posmask); }
+  __device__ __forceinline__ u32 elem_prev(u64 x, u32) const { return ((u32)x >> pbits) & 0xFFu; }
   __device__ __forceinline__ u64 cvt(u64 x) const { return (x & 0xFFFFFFFF00000000ull) | ((u32)x >> pbits); }
   __device__ __forceinline__ u64 key(size_t i) const { return cvt(e[i]); }
   __device__ __forceinline__ u32 pos(size_t i) const { return sa ? sa[i] : a + ((u32)e[i] & posmask); }
@@ -120,6 +125,19 @@ struct PackedView {
       for (int j = 0; j < 4; j++) p[j] = a + ((u32)x[j] & posmask);
     }
   }
+};
+
+// Wide elements (TextKeys::wide) sorted on their top bbits key bits; only the bucket kernel reads them.
+struct WideView {
+  const u64 *e;    // | key bits 63..32 | absolute position |
+  const u8 *side;  // | key bits 31..28 | preceding symbol |
+  int kshift;      // 20 - bbits: the 16 key bits below the bucket's start this far up in the 36-bit key
+  static constexpr bool WIDE = true;
+  __device__ __forceinline__ u32 bucket_key(u64 x, u32 sd) const {
+    return (u32)((((x >> 32) << 4) | (sd >> 4)) >> kshift) & 0xFFFFu;
+  }
+  __device__ __forceinline__ u32 elem_pos(u64 x) const { return (u32)x; }
+  __device__ __forceinline__ u32 elem_prev(u64, u32 sd) const { return sd & 15u; }
 };
 
 __device__ __host__ inline void set_positions(PairsView &, const u32 *) {}
@@ -650,15 +668,33 @@ __global__ void __launch_bounds__(DE_THREADS) k_direct_emit(LeafEmit<View> E, co
 // are emitted where they stand, tied ones by LeafEmit::direct_tied.  Groups of equal keys never straddle
 // buckets.  slack_before[k] = window-slack positions in the buckets below k.
 // ----------------------------------------------------------------------------
-struct BucketWindow {  // the bucket from LDS, anything else (never a match) from memory
+template <class V>
+struct BucketWindow;
+template <>
+struct BucketWindow<PackedView> {  // the bucket from LDS, anything else (never a match) from memory
   const PackedView &v;
   const u64 *buf;
+  const u8 *sbuf;
   u64 s;
   u32 cnt;
   __device__ __forceinline__ u64 key(u64 i) const { return i - s < (u64)cnt ? v.cvt(buf[i - s]) : v.key(i); }
   __device__ __forceinline__ u32 pos(u64 i) const {
     return i - s < (u64)cnt ? v.a + ((u32)buf[i - s] & v.posmask) : v.pos(i);
   }
+};
+template <>
+struct BucketWindow<WideView> {  // key = | the bucket's 16 sorted key bits | preceding symbol, 8 bits |; outside the bucket: no match
+  const WideView &v;
+  const u64 *buf;
+  const u8 *sbuf;
+  u64 s;
+  u32 cnt;
+  __device__ __forceinline__ u64 key(u64 i) const {
+    if (i - s >= (u64)cnt) return ~0ull;
+    const u32 sd = sbuf[i - s];
+    return ((u64)v.bucket_key(buf[i - s], sd) << 8) | (sd & 15u);
+  }
+  __device__ __forceinline__ u32 pos(u64 i) const { return i - s < (u64)cnt ? (u32)buf[i - s] : 0u; }
 };
 
 // index of the k-th set bit of m (k below its population count)
@@ -688,9 +724,11 @@ __device__ __forceinline__ u32 select_bit(u64 m, u32 k) {
 
 // ITEMS: elements per thread; the caller takes the smallest variant that holds the largest bucket, because
 // empty element slots still cost their instructions.
-template <bool SLACK, int ITEMS>
+template <class V, bool SLACK, int ITEMS>
 __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
-    k_bucket_emit(LeafEmit<PackedView> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before) {
+    k_bucket_emit(LeafEmit<V> E, const u32 *__restrict__ start, const u32 *__restrict__ slack_before) {
+  constexpr bool WIDE = V::WIDE;
+  __shared__ u8 sbuf[WIDE ? ITEMS * BK_THREADS : 1];  // the side bytes of the sorted bucket
   constexpr int BK_MASKS = ITEMS * BK_WAVES;  // one 64-bit flag word per wave and round
   constexpr int BUF_ELEMS = ITEMS * BK_THREADS > 6144 ? ITEMS * BK_THREADS : 6144;  // the counters need 48 KB
   __shared__ __align__(16) u64 buf[BUF_ELEMS];
@@ -703,6 +741,8 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 wbase = w * (64 * ITEMS);
   const u64 *mine = E.v.e + s;
+  const u8 *mine_side = nullptr;
+  if constexpr (WIDE) mine_side = E.v.side + s;
   {
     // Order of the bucket by the 16 key bits below the bucket's own (zero padding included when the key is
     // shorter).  No order is needed among equal keys -- ties are decided on the text -- so one counting round
@@ -715,10 +755,12 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     u32 *nib = reinterpret_cast<u32 *>(buf);
     u16 *wpre = reinterpret_cast<u16 *>(nib + NIB_WORDS);  // counters in the words below word j
     u64 key[ITEMS];
+    u8 sd[WIDE ? ITEMS : 1];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
       const u32 idx = wbase + r * 64 + lane;
       key[r] = idx < cnt ? mine[idx] : 0ull;
+      if constexpr (WIDE) sd[r] = idx < cnt ? mine_side[idx] : (u8)0;
     }
     reinterpret_cast<uint4 *>(nib)[tid * 2] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4 *>(nib)[tid * 2 + 1] = make_uint4(0, 0, 0, 0);
@@ -733,7 +775,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
       if (wbase + r * 64 + lane < cnt) {
-        const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
+        const u32 k = E.v.bucket_key(key[r], WIDE ? sd[r] : 0u), sh = (k & 7) * 4;
         const u32 old = (atomicAdd(&nib[k >> 3], 1u << sh) >> sh) & 15u;
         full = full || old == 15u;
         ord |= (u64)old << (4 * r);
@@ -773,7 +815,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     u32 pos[ITEMS], tied_in = 0;
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
-      const u32 k = (u32)(key[r] >> 32) & 0xFFFFu, sh = (k & 7) * 4;
+      const u32 k = E.v.bucket_key(key[r], WIDE ? sd[r] : 0u), sh = (k & 7) * 4;
       const u32 word = nib[k >> 3];
       const u32 below = word & ((1u << sh) - 1u);
       const u32 y = (below & 0x0F0F0F0Fu) + ((below >> 4) & 0x0F0F0F0Fu);
@@ -786,8 +828,9 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     for (int r = 0; r < ITEMS; r++) {
       if (wbase + r * 64 + lane < cnt) {
         buf[pos[r]] = key[r];
+        if constexpr (WIDE) sbuf[pos[r]] = sd[r];
         if ((tied_in >> r) & 1u) atomicOr(&tied32[pos[r] >> 5], 1u << (pos[r] & 31u));
-        if (SLACK && E.v.a + ((u32)key[r] & E.v.posmask) >= E.leaf_end) atomicOr(&slack32[pos[r] >> 5], 1u << (pos[r] & 31u));
+        if (SLACK && E.v.elem_pos(key[r]) >= E.leaf_end) atomicOr(&slack32[pos[r] >> 5], 1u << (pos[r] & 31u));
       }
     }
     lds_barrier();
@@ -821,7 +864,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
       const u64 me = buf[idx];
       u32 sb = below;
       if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
-      if (E.place_fast((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask), ((u32)me >> E.v.pbits) & 0xFFu)) look |= 1u << r;
+      if (E.place_fast((u64)s + idx - sb, E.v.elem_pos(me), E.v.elem_prev(me, WIDE ? sbuf[idx] : 0u))) look |= 1u << r;
     }
   }
   while (look) {  // usually one pass per wave instead of one per round
@@ -831,10 +874,10 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     const u64 me = buf[idx];
     u32 sb = below;
     if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
-    E.note_sample((u64)s + idx - sb, E.v.a + ((u32)me & E.v.posmask));
+    E.note_sample((u64)s + idx - sb, E.v.elem_pos(me));
   }
   const u32 all_tied = tied_pre[BK_MASKS];
-  const BucketWindow win{E.v, buf, (u64)s, cnt};
+  const BucketWindow<V> win{E.v, buf, sbuf, (u64)s, cnt};
   for (u32 t = tid; t < all_tied; t += BK_THREADS) {
     u32 lo = 0, hi = BK_MASKS;  // the last flag word whose prefix is <= t
     while (hi - lo > 1) {
@@ -947,21 +990,22 @@ static KeyPlan plan_keys(int span, int raw_bits, u64 N) {  // span = max_sym - m
   return best;
 }
 
-template <bool SLACK>
-static void launch_bucket_emit(Ctx &c, const LeafEmit<PackedView> &em, u32 max_bucket, const u32 *start, const u32 *slack_before) {
+template <class V, bool SLACK>
+static void launch_bucket_emit(Ctx &c, const LeafEmit<V> &em, u32 n_buckets, u32 max_bucket, const u32 *start, const u32 *slack_before) {
   const u32 items = ceil_div(max_bucket ? max_bucket : 1, BK_THREADS);
-  if (items > (u32)BK_ITEMS) fail(BWT_HIP_EINTERNAL, "bucket of %u elements", max_bucket);
-  const dim3 grid(BK_BUCKETS), block(BK_THREADS);
+  constexpr u32 MAX_ITEMS = V::WIDE ? 8 : BK_ITEMS;  // a wide bucket also keeps its side bytes in LDS
+  if (items > MAX_ITEMS) fail(BWT_HIP_EINTERNAL, "bucket of %u elements", max_bucket);
+  const dim3 grid(n_buckets), block(BK_THREADS);
   if (c.timing_level >= 2) {  // a counter, not a timer: which instantiation the bucket sizes selected
     const u32 variant = items <= 4 ? 4 : (items <= 6 ? 6 : (items <= 8 ? 8 : (u32)BK_ITEMS));
     char name[64];
-    snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s", variant, SLACK ? ",slack" : "");
+    snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s%s", variant, SLACK ? ",slack" : "", V::WIDE ? ",wide" : "");
     c.timers[(size_t)c.timer_index(name)].launches++;
   }
-  if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
-  else if (items <= 6) hipLaunchKernelGGL((k_bucket_emit<SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
-  else if (items <= 8) hipLaunchKernelGGL((k_bucket_emit<SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);
-  else hipLaunchKernelGGL((k_bucket_emit<SLACK, BK_ITEMS>), grid, block, 0, c.stream, em, start, slack_before);
+  if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items <= 6) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items <= 8) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);
+  else if constexpr (!V::WIDE) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, BK_ITEMS>), grid, block, 0, c.stream, em, start, slack_before);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1005,13 +1049,13 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
         from_buckets = true;
         KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
         if (e == b) {
-          launch_bucket_emit<false>(c, em, bs->max_bucket, bs->start.get(), nullptr);
+          launch_bucket_emit<PackedView, false>(c, em, BK_BUCKETS, bs->max_bucket, bs->start.get(), nullptr);
         } else {
           DBuf<u32> sb(c, BK_BUCKETS);
           HIP_CHECK(hipMemsetAsync(sb.get(), 0, BK_BUCKETS * sizeof(u32), c.stream));
           bucket_histogram(c, *tk, (u64)b, (u64)(e - b), 16, sb.get());
           scan_generic<u32, SumU32>(c, BK_BUCKETS, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, BK_BUCKETS});
-          launch_bucket_emit<true>(c, em, bs->max_bucket, bs->start.get(), sb.get());
+          launch_bucket_emit<PackedView, true>(c, em, BK_BUCKETS, bs->max_bucket, bs->start.get(), sb.get());
         }
       }
     }
@@ -1130,6 +1174,78 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   return true;
 }
 
+// Wide bucket route: windows that the packed 8-byte elements cannot index (more than 2^29 suffixes of DNA) but
+// whose symbols are small.  Elements of 8 + 1 bytes (TextKeys::wide) go through three radix passes on their
+// top bbits key bits; a bucket then holds a few thousand suffixes, is ordered in LDS on the next 16 key bits
+// and emitted by k_bucket_emit like a bucket of the packed route; whatever those bbits + 16 bits leave tied
+// is decided on the text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing
+// usable was written and the caller sorts the window as (key, position) pairs.
+static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
+  if (c.max_sym > 15 || N < c.bucket_min_n || N < 2) return 0;
+  const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
+  const int one_based = pow2 ? 0 : 1;
+  const int w = bits_for((u64)(span + one_based));
+  // Buckets of 3500 to 7000 suffixes: larger buckets leave more ties to the text comparisons but cost less per
+  // suffix (1.55e9 suffixes: 21 ms with 2^18 buckets, 25 ms with 2^19, 42 ms with 2^20).
+  int bbits = 17;
+  while (bbits < 24 && (N >> bbits) > 7000) bbits++;
+  if (c.wide_bbits) bbits = c.wide_bbits;
+  if ((N >> bbits) > 7000) return 0;
+  const int h = (bbits + 16) / w;  // symbols covered by the bits the buckets are ordered on
+  const int K0 = 36 / w;
+  if (h < 1 || h > K0) return 0;
+  const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
+  if (expected_ties(sigma, h, N) > 0.25) return 0;
+  constexpr u32 CAP = 8 * BK_THREADS;
+  TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0, min_sym, one_based, 0};
+  tk.wide = 1;
+  DBuf<u64> eb0(c, N), eb1(c, N);
+  DBuf<u8> sb0(c, N), sb1(c, N);
+  u64 *el[2] = {eb0.get(), eb1.get()};
+  u8 *sd[2] = {sb0.get(), sb1.get()};
+  BucketState bs;
+  int cur;
+  {
+    Phase ph(c, "leaf_radix_sort", (double)N * (1 + 1 + 10 + 1 + 18 + 8 + 18));
+    cur = leaf_sort_text_wide(c, el, sd, N, bbits, CAP, tk, &bs);
+  }
+  if (cur < 0) return 0;
+  const u32 n_buckets = 1u << bbits;
+  u32 *d_fail = c.d_scalars + 10;
+  DBuf<u32> res;
+  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
+  Phase ph(c, "leaf_direct_emit", (double)N * 9 + (double)(b - a) * 2);
+  LeafEmit<WideView> em;
+  memset(&em, 0, sizeof(em));
+  if (E) static_cast<EmitParams &>(em) = *E;
+  em.sa_out = sa_out ? res.get() : nullptr;
+  em.v = WideView{el[cur], sd[cur], 20 - bbits};
+  em.N = N;
+  em.sym_mask = ~0xFFull;  // BucketWindow<WideView>::key: the ordered key bits above the preceding symbol
+  em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
+  em.h = (u64)h;
+  em.leaf_end = (u32)b;
+  em.fail = d_fail;
+  em.T = c.T;
+  em.n = (u64)c.n;
+  HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+  {
+    KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 9 + (double)(b - a));
+    if (e == b) {
+      launch_bucket_emit<WideView, false>(c, em, n_buckets, bs.max_bucket, bs.start.get(), nullptr);
+    } else {
+      DBuf<u32> sb(c, n_buckets);
+      HIP_CHECK(hipMemsetAsync(sb.get(), 0, (size_t)n_buckets * sizeof(u32), c.stream));
+      bucket_histogram(c, tk, (u64)b, (u64)(e - b), 16, sb.get(), bbits);
+      scan_generic<u32, SumU32>(c, n_buckets, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, n_buckets});
+      launch_bucket_emit<WideView, true>(c, em, n_buckets, bs.max_bucket, bs.start.get(), sb.get());
+    }
+  }
+  if (read_u32(c, d_fail) != 0) return 0;
+  if (sa_out) *sa_out = std::move(res);
+  return 1;
+}
+
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
 static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out) {
@@ -1143,6 +1259,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   const int begin_bit = low_bit & ~7;  // whole digits; the extra low bits are zero padding
   const int passes = (64 - begin_bit) / 8;
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
+  if ((!kp.pbits || c.force_wide) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
     DBuf<u64> eb0(c, N), eb1(c, N);

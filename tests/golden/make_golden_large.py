@@ -39,6 +39,7 @@ CASES = [
 
 # name, recipe, a, b, ssa_n_samples: one leaf.  b < n gives the GPU sort a window that is longer than the leaf.
 LEAF_CASES = [
+    ("leaf_s4_whole_5.3e8", {"kind": "splitmix", "n": 530000000, "seed": 42, "sigma": 4}, 0, 530000000, 1000000),
     ("leaf_s4_whole_5.6e8", {"kind": "splitmix", "n": 560000000, "seed": 42, "sigma": 4}, 0, 560000000, 1000000),
     ("leaf_s4_first_5e8_of_5.01e8", {"kind": "splitmix", "n": 501000000, "seed": 42, "sigma": 4}, 0, 500000000, 1000000),
     ("leaf_s4_mid_3.6e8", {"kind": "splitmix", "n": 400000000, "seed": 7, "sigma": 4}, 20000000, 380000000, 500000),
@@ -88,6 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=5)
     ap.add_argument("--group", default="all", choices=["all", "pipeline", "leaf"])
+    ap.add_argument("--only", default="", help="comma-separated case names: regenerate these and keep the group's others")
     args = ap.parse_args()
     from oracle import Reference
     assert Reference.available(), "build oracle/_ref first (make -C oracle)"
@@ -99,10 +101,15 @@ def main():
     out["generator"] = "tests/golden/make_golden_large.py"
     out["source"] = "taura/bwt compiled serially from its own headers (oracle/ref_harness.cc)"
     with Pool(args.jobs) as pool:
-        if args.group in ("all", "pipeline"):
-            out["pipeline"] = pool.map(run_case, CASES, chunksize=1)
-        if args.group in ("all", "leaf"):
-            out["leaf"] = pool.map(run_leaf_case, LEAF_CASES, chunksize=1)
+        only = set(x for x in args.only.split(",") if x)
+        for group, fn, cases in (("pipeline", run_case, CASES), ("leaf", run_leaf_case, LEAF_CASES)):
+            if args.group not in ("all", group):
+                continue
+            todo = [c for c in cases if not only or c[0] in only]
+            new = {r["name"]: r for r in pool.map(fn, todo, chunksize=1)}
+            old = {r["name"]: r for r in out[group]} if only else {}
+            old.update(new)
+            out[group] = [old[c[0]] for c in cases if c[0] in old]
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -16,3 +16,13 @@ def test_bucket_route_on_small_texts():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "bucket route ok" in r.stdout
+
+
+def test_wide_bucket_route_on_small_texts():
+    """The route of windows above 2^29 suffixes (8 + 1 byte elements, three passes, 2^17 and more buckets), forced
+    onto small texts."""
+    env = dict(os.environ, BWT_HIP_BUCKET_MIN_N="1", BWT_HIP_FORCE_WIDE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "wide_route_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "wide route ok" in r.stdout

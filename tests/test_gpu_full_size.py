@@ -56,16 +56,20 @@ def test_golden_large_pipeline(timed, rec):
 
 @pytest.mark.parametrize("rec", GL.get("leaf", []), ids=lambda r: r["name"])
 def test_golden_large_leaf(timed, rec):
-    """bwt_leaf on windows whose buckets hold 5500 to 8600 suffixes: the 6-, 8- and 9-element instantiations of
-    k_bucket_emit, with and without window slack, against the reference's leaf (L, special ranks, samples)."""
+    """bwt_leaf on windows whose buckets hold 5500 to 8500 suffixes: the 6-, 8- and 9-element instantiations of
+    k_bucket_emit, with and without window slack, and one window above 2^29 suffixes, against the reference's
+    leaf (L, special ranks, samples)."""
     ctx = timed
     t = rec["text"]
     ctx.gen_text(t["n"], t["seed"], t["sigma"])
     blk = ctx.leaf(rec["a"], rec["b"], rec["ssa_n_samples"])
     check_block(blk, blk.L, rec, 0, rec["b"] - rec["a"])
-    want = {"leaf_s4_whole_5.6e8": "leaf:bucket_emit_items=9", "leaf_s4_first_5e8_of_5.01e8": "leaf:bucket_emit_items=8,slack",
-            "leaf_s4_mid_3.6e8": "leaf:bucket_emit_items=6,slack"}[rec["name"]]
-    assert launches(ctx, "leaf:k_bucket_emit") == 1 and variants(ctx) == [want]
+    # 5.6e8 suffixes are more than the packed 8-byte elements hold positions for (2^29): that window takes the wide
+    # route (8 + 1 byte elements, 2^17 buckets)
+    want = {"leaf_s4_whole_5.3e8": ["leaf:bucket_emit_items=9"], "leaf_s4_whole_5.6e8": ["leaf:bucket_emit_items=6,wide"],
+            "leaf_s4_first_5e8_of_5.01e8": ["leaf:bucket_emit_items=8,slack"],
+            "leaf_s4_mid_3.6e8": ["leaf:bucket_emit_items=6,slack"]}[rec["name"]]
+    assert launches(ctx, "leaf:k_bucket_emit") == len(want) and variants(ctx) == want
     blk.free()
 
 
@@ -98,6 +102,7 @@ def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves):
     blk, L, r, p, info = _build(ctx, n, leaves, ns)
     got = variants(ctx)
     ctx.set_timing(0)
+    ctx.trim()
     assert launches(ctx, "leaf:k_bucket_emit") == leaves and got == expect_variants, got
     # decoded on the device, L gives the text back (src/pmbwt.cc:64-81 check_result)
     assert blk.ibwt_mismatches() == 0
@@ -140,4 +145,11 @@ def test_config2_n1e9_two_leaves(ctx):
 def test_config3_n3_1e9_eight_leaves(ctx):
     """Config 3 on one GPU as bench.py runs it by default: 8 leaves of 3.875e8 suffixes, 7 merges."""
     _full_size(ctx, 3100000000, 8, 19375000, ["leaf:bucket_emit_items=8", "leaf:bucket_emit_items=8,slack"], 4)
+    ctx.trim()
+
+
+def test_n3_1e9_two_leaves_wide_route(ctx):
+    """bench.py's default on one GPU: 3.1e9 symbols as two leaves of 1.55e9 suffixes (more than 2^29: the wide
+    bucket route, 2^18 buckets) and one merge; against the same tree sorted as (key, position) pairs."""
+    _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=6,wide", "leaf:bucket_emit_items=6,slack,wide"], 8)
     ctx.trim()
