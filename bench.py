@@ -6,10 +6,11 @@ Metric: Mbase/s = (n-1) / seconds per build.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n N_CHARS] [--sigma S] [--leaves P]
 
-Default workload, the same for every N: random DNA of n = 3.1e9 symbols (GRCh38-sized) cut into 8 leaves
-of 3.875e8 suffixes and merged by a tree of 7 gap-array merges.  On one GPU the whole tree runs there; on
-N GPUs (launched by torch.distributed.run, one rank per GPU) every rank builds 8/N leaves and each merge of
-the upper levels runs on all GPUs of its subtree (bwt_amd/dist_merge.py): strong scaling of one text.
+Default workload: random DNA of n = 3.1e9 symbols (GRCh38-sized), the same text for every N, cut into
+max(2, N) leaves: one leaf per GPU, and two leaves plus their merge on one GPU, so that every kernel of the
+path runs there too.  On N GPUs (launched by torch.distributed.run, one rank per GPU) every rank builds its
+leaf and each merge of the tree runs on all GPUs of its subtree (bwt_amd/dist_merge.py): strong scaling of
+one text.  `--leaves 8` gives the 8-leaf tree (3.875e8 suffixes per leaf, 7 merges) on any N that divides 8;
 `--n 1000000000 --leaves 2` is the one-GPU configuration "leaf sort + single gap-array merge".
 
 `value` is measured with the text already in HBM and the result left in HBM.  The same line also carries
@@ -29,7 +30,6 @@ sys.path.insert(0, ROOT)
 
 METRIC = "BWT build Mbase/s end-to-end, 3.1 Gbp DNA, at 1/2/4/8 MI355X"
 DEFAULT_N = 3100000000
-DEFAULT_LEAVES = 8
 
 
 class stdout_to_stderr:
@@ -147,8 +147,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--text_len", "--n", dest="n", type=int, default=DEFAULT_N, help="text length (default 3.1e9)")
     ap.add_argument("--sigma", type=int, default=4)
-    ap.add_argument("--leaves", type=int, default=DEFAULT_LEAVES,
-                    help="leaves of the whole tree (a power of two, at least one per GPU; default 8)")
+    ap.add_argument("--leaves", type=int, default=None,
+                    help="leaves of the whole tree (a power of two, at least one per GPU; default max(2, GPUs))")
     ap.add_argument("--ssa_n_samples", type=int, default=0)
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--cpu_n", type=int, default=3 * 10 ** 7, help="sample size of the CPU baseline (0 = skip)")
@@ -164,6 +164,8 @@ def main():
             print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus),
                   file=sys.stderr)
             sys.exit(2)
+    if args.leaves is None:
+        args.leaves = max(2, world)
     if args.leaves < 1 or args.leaves & (args.leaves - 1) or args.leaves % world:
         print("--leaves %d: must be a power of two and a multiple of the %d GPUs" % (args.leaves, world), file=sys.stderr)
         sys.exit(2)
@@ -206,10 +208,10 @@ def main():
     }
     if not args.no_extras:
         out["host_to_host"] = host_to_host(ctx, n, th, ns, args.seg, min(args.steps, 3))
-        # the same text as fewer, larger leaves (one step each after one untimed build)
+        # the same text as other trees (one step each after one untimed build)
         other = {}
-        for leaves in (2, 1):
-            if leaves >= args.leaves:
+        for leaves in (8, 1):
+            if leaves == args.leaves:
                 continue
             th2, ns2 = -(-n // leaves), default_samples(n, leaves)
             ctx.pmbwt(th2, ns2, args.seg).free()
