@@ -37,9 +37,29 @@ static void need(bool cond, const char *what) {
   if (!cond) fail(BWT_HIP_EINVAL, "invalid argument: %s", what);
 }
 
+// Every block handed out through the C-ABI, with its context: destroying a context frees the blocks that are still
+// alive in it, and freeing a handle that is no longer registered (its context went first) does nothing.
+#include <mutex>
+#include <set>
+static std::mutex g_blocks_mu;
+static std::map<Block *, Ctx *> g_blocks;
+
 static Block *as_block(bwt_hip_block *b) { return reinterpret_cast<Block *>(b); }
 static const Block *as_block(const bwt_hip_block *b) { return reinterpret_cast<const Block *>(b); }
 static bwt_hip_block *as_handle(Block *b) { return reinterpret_cast<bwt_hip_block *>(b); }
+
+static bwt_hip_block *publish(Ctx &c, Block *b) {
+  std::lock_guard<std::mutex> lock(g_blocks_mu);
+  g_blocks[b] = &c;
+  return as_handle(b);
+}
+// a block that a call consumes (merge) leaves the registry with the call
+static Block *take(bwt_hip_block *h) {
+  Block *b = as_block(h);
+  std::lock_guard<std::mutex> lock(g_blocks_mu);
+  if (g_blocks.erase(b) == 0) fail(BWT_HIP_EINVAL, "block handle %p is not alive (freed, merged, or its context was destroyed)", (void *)h);
+  return b;
+}
 
 // ---------------------------------------------------------------------------
 // context
@@ -75,6 +95,19 @@ void bwt_hip_destroy(bwt_hip_ctx *ctx) {
   Ctx &c = ctx->c;
   (void)hipSetDevice(c.device);
   (void)hipStreamSynchronize(c.stream);
+  {
+    std::vector<Block *> mine;
+    std::lock_guard<std::mutex> lock(g_blocks_mu);
+    for (auto it = g_blocks.begin(); it != g_blocks.end();) {
+      if (it->second == &c) {
+        mine.push_back(it->first);
+        it = g_blocks.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    for (Block *b : mine) delete b;
+  }
   for (auto &p : c.pending) {
     (void)hipEventDestroy(p.e0);
     (void)hipEventDestroy(p.e1);
@@ -211,7 +244,7 @@ int bwt_hip_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ns, bwt_hip_blo
   API_BEGIN
   need(ctx && out, "ctx, out");
   HIP_CHECK(hipSetDevice(ctx->c.device));
-  *out = as_handle(do_leaf(ctx->c, a, b, ns));
+  *out = publish(ctx->c, do_leaf(ctx->c, a, b, ns));
   API_END
 }
 
@@ -220,7 +253,15 @@ int bwt_hip_merge(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t 
   API_BEGIN
   need(ctx && l && r && out, "ctx, l, r, out");
   HIP_CHECK(hipSetDevice(ctx->c.device));
-  *out = as_handle(do_merge(ctx->c, as_block(l), as_block(r), ns, seg));
+  need(l != r, "l and r are the same block");
+  Block *lb = take(l), *rb = nullptr;
+  try {
+    rb = take(r);
+  } catch (...) {
+    publish(ctx->c, lb);
+    throw;
+  }
+  *out = publish(ctx->c, do_merge(ctx->c, lb, rb, ns, seg));
   API_END
 }
 
@@ -231,7 +272,7 @@ int bwt_hip_rec(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t th, int64_t ns, 
   need(a >= 0 && a < b && b <= ctx->c.n, "0 <= a < b <= n");
   need(th >= 1, "bwt_rec_threshold >= 1");
   HIP_CHECK(hipSetDevice(ctx->c.device));
-  *out = as_handle(do_rec(ctx->c, a, b, th, ns, seg));
+  *out = publish(ctx->c, do_rec(ctx->c, a, b, th, ns, seg));
   API_END
 }
 
@@ -276,7 +317,7 @@ int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
   c.sync();
   blk->e_char = *(u8 *)c.h_scalars;
-  *out = as_handle(blk.release());
+  *out = publish(c, blk.release());
   API_END
 }
 
@@ -344,12 +385,17 @@ int bwt_hip_block_import_device(bwt_hip_ctx *ctx, int64_t a, int64_t b, const ui
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
   c.sync();
   blk->e_char = *(u8 *)c.h_scalars;
-  *out = as_handle(blk.release());
+  *out = publish(c, blk.release());
   API_END
 }
 
 void bwt_hip_block_free(bwt_hip_ctx *ctx, bwt_hip_block *blk) {
   (void)ctx;
+  if (!blk) return;
+  {
+    std::lock_guard<std::mutex> lock(g_blocks_mu);
+    if (g_blocks.erase(as_block(blk)) == 0) return;  // already gone with its context
+  }
   delete as_block(blk);
 }
 

@@ -128,6 +128,23 @@ namespace bwt {
       return k;
     }
 
+    /* Positions of T[a:b) that L does not decode to, plus samples that are not where the decoding passes:
+       0 iff L and the sample table describe T[a:b).  Decoded on the device, one LF walk per sample, while the
+       block is still in HBM (no init_extra needed); by ibwt() on the host otherwise (after init_extra). */
+    idx_t round_trip_mismatches() {
+      if (dev) {
+        int64_t bad = -1;
+        bwt_hip_ok(bwt_hip_block_ibwt(device_session::get().ctx, dev, 0, &bad));
+        return (idx_t)bad;
+      }
+      alpha_t * I = new alpha_t[b - a];
+      ibwt(I - a);
+      idx_t bad = 0;
+      for (idx_t j = a; j < b; j++) bad += (I[j - a] != T[j]);
+      delete[] I;
+      return bad;
+    }
+
     /* inverse transform of the block into I[a:b) */
     void ibwt(alpha_t * I) {
       idx_t r = e_rank;
@@ -238,7 +255,7 @@ namespace bwt {
   inline bwt bwt_leaf(const alpha_t * T, idx_t n, idx_t a, idx_t b, alpha_t * L, mallocator & mem, bwt_opt & opt) {
     stat.start(ts_event_bwt_leaf);
     assert(a < b);
-    bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device);
+    bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device, !device_session::get().text_is_stable);
     bwt_hip_block * h = 0;
     bwt_hip_ok(bwt_hip_leaf(c, a, b, opt.ssa_n_samples, &h));
     bwt res;
@@ -276,7 +293,7 @@ namespace bwt {
                      mallocator & mem, bwt_opt & opt) {
     (void)W;
     stat.start(ts_event_bwt_range_rec);
-    bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device);
+    bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device, !device_session::get().text_is_stable);
     bwt_hip_block * h = 0;
     bwt_hip_ok(bwt_hip_rec(c, a, b, opt.bwt_rec_threshold, opt.ssa_n_samples, opt.build_gap_segment_sz, &h));
     bwt t;
@@ -286,25 +303,33 @@ namespace bwt {
     return t;
   }
 
-  /* credits the device's phase timers to the reference's event names */
+  /* credits the device's phase timers to the reference's event names; a phase the table does not know goes to
+     the event of its family (leaf_*, gap_*, merge_*), so that no device time is dropped from the table */
   inline void credit_device_timers(bwt_hip_ctx * c, double clocks_per_ms) {
     struct map_t { const char * phase; ts_event_kind_t ev; };
     static const map_t table[] = {
-      { "leaf_key_build", ts_event_bwt_leaf }, { "leaf_radix_sort", ts_event_bwt_leaf },
-      { "leaf_group", ts_event_bwt_leaf }, { "leaf_text_round", ts_event_bwt_leaf },
-      { "leaf_doubling_round", ts_event_bwt_leaf }, { "leaf_window_filter", ts_event_bwt_leaf },
-      { "leaf_sa_to_bwt", ts_event_bwt_sample_sa },
+      { "leaf_radix_sort", ts_event_bwt_leaf }, { "leaf_group", ts_event_bwt_leaf },
+      { "leaf_text_round", ts_event_bwt_leaf }, { "leaf_doubling_round", ts_event_bwt_leaf },
+      /* the passes that turn the sorted window into L, s_rank/e_rank and the samples (sa_to_bwt + sample_sa) */
+      { "leaf_direct_emit", ts_event_bwt_sample_sa }, { "leaf_emit", ts_event_bwt_sample_sa },
       { "count_alphabets", ts_event_bwt_count_alphabets },
       { "wavelet_build", ts_event_bwt_build_wavelet_matrix },
       { "gap_chains", ts_event_bwt_build_gap }, { "gap_histogram", ts_event_gap_array_set_prefix_sum },
       { "merge_scatter", ts_event_bwt_merge_loop }, { "merge_resample", ts_event_bwt_resample_sa },
     };
+    static const map_t family[] = {
+      { "leaf_", ts_event_bwt_leaf }, { "gap_", ts_event_bwt_build_gap }, { "merge_", ts_event_bwt_merge_bwt },
+    };
     int k = bwt_hip_timer_count(c);
     for (int i = 0; i < k; i++) {
       const char * name; double ms, work; int64_t calls;
-      if (bwt_hip_timer_get(c, i, &name, &ms, &work, &calls) != 0) continue;
-      for (size_t j = 0; j < sizeof(table) / sizeof(table[0]); j++)
-        if (strcmp(table[j].phase, name) == 0) stat.add(table[j].ev, (tsc_t)(ms * clocks_per_ms), (long)calls);
+      if (bwt_hip_timer_get(c, i, &name, &ms, &work, &calls) != 0 || calls == 0) continue;
+      if (strchr(name, ':') || strchr(name, '=')) continue; /* per-kernel timers and counters lie inside a phase */
+      bool done = false;
+      for (size_t j = 0; j < sizeof(table) / sizeof(table[0]) && !done; j++)
+        if (strcmp(table[j].phase, name) == 0) { stat.add(table[j].ev, (tsc_t)(ms * clocks_per_ms), (long)calls); done = true; }
+      for (size_t j = 0; j < sizeof(family) / sizeof(family[0]) && !done; j++)
+        if (strncmp(family[j].phase, name, strlen(family[j].phase)) == 0) { stat.add(family[j].ev, (tsc_t)(ms * clocks_per_ms), (long)calls); done = true; }
     }
   }
 

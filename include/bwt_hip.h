@@ -44,6 +44,8 @@ const char *bwt_hip_last_error(void);
    reference (which has no device); lifetime brackets what `mallocator mem`
    brackets in src/pmbwt.cc:317-332. */
 int bwt_hip_create(int device, bwt_hip_ctx **out);
+/* Also frees every block of the context that is still alive; their handles become invalid, and
+   bwt_hip_block_free on such a handle does nothing. */
 void bwt_hip_destroy(bwt_hip_ctx *ctx);
 
 /* Page-locked host memory for T and L: copies between such buffers and the device run at the link's rate

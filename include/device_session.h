@@ -2,9 +2,15 @@
    libbwt_hip.so: one device context, and the text it currently holds.
 
    The reference needs nothing like this (it has no device).  The header API
-   passes `const alpha_t * T, idx_t n` to every call; the session uploads T the
-   first time it sees a (pointer, length, content signature) and reuses the
-   device copy afterwards.  Failures of the C-ABI are reported the way the
+   passes `const alpha_t * T, idx_t n` to every call.  pmbwt, bwt_leaf and bwt_rec
+   upload T every time (n bytes: little next to the build), because a caller may
+   have rewritten the buffer in place between two calls; bwt_merge, which can
+   only follow them, reuses the device copy while (pointer, length, sampled
+   signature) stay the same.  A caller that builds many leaves of one unchanged
+   text sets `device_session::get().text_is_stable = true` to skip the repeated
+   uploads.  Switching the device (opt.device) destroys the old context together
+   with every device block still alive in it: struct bwt objects from before the
+   switch keep their host data, and their fini() stays valid.  Failures of the C-ABI are reported the way the
    reference reports failures: message on stderr, abort() (include/util.h:26-36
    of the reference). */
 #pragma once
@@ -32,8 +38,9 @@ namespace bwt {
     const alpha_t * T;
     idx_t n;
     uint64_t sig;
+    bool text_is_stable; /* the caller promises not to modify T between calls */
 
-    device_session() : ctx(0), device(-1), T(0), n(0), sig(0) {}
+    device_session() : ctx(0), device(-1), T(0), n(0), sig(0), text_is_stable(false) {}
     ~device_session() { if (ctx) bwt_hip_destroy(ctx); }
 
     static device_session & get() { static device_session s; return s; }

@@ -12,6 +12,8 @@
 #pragma once
 
 #include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "typedefs.h"
 #include "util.h"
@@ -53,13 +55,32 @@ namespace bwt {
 
     sampled_suffix_array() : n(0), sz(0), log_sz(0), a(0), begin(0), end(0) {}
 
+    /* runs body(t, nt) on nt host threads (the calling one included) when there is enough work for them */
+    template <class F>
+    static void on_threads(idx_t work, F body) {
+      unsigned hw = std::thread::hardware_concurrency();
+      idx_t nt = work < ((idx_t)1 << 20) ? 1 : (hw > 16 ? 16 : (hw < 1 ? 1 : (idx_t)hw));
+      std::vector<std::thread> th;
+      for (idx_t t = 1; t < nt; t++) th.push_back(std::thread(body, t, nt));
+      body((idx_t)0, nt);
+      for (size_t t = 0; t < th.size(); t++) th[t].join();
+    }
+
+    struct fill_body {
+      ssa_entry * a; idx_t sz;
+      void operator() (idx_t t, idx_t nt) const {
+        for (idx_t i = sz * t / nt; i < sz * (t + 1) / nt; i++) a[i].rank = a[i].pos = -1;
+      }
+    };
+
     void init(idx_t sz_req, mallocator & mem, idx_t init_gran = 10000) {
       (void)init_gran;
       n = 0;
       log_sz = calc_log_sample_sa_sz(sz_req);
       sz = (idx_t)1 << (log_sz + 1);
       a = mem.new_<ssa_entry>(sz, mem_reason_sample_sa);
-      for (idx_t i = 0; i < sz; i++) a[i].rank = a[i].pos = -1;
+      fill_body fb = { a, sz };
+      on_threads(sz, fb); /* first touch of up to gigabytes of fresh pages */
       begin = 0;
       end = a + sz;
     }
@@ -140,11 +161,39 @@ namespace bwt {
       return ssa_iterator(begin, end);
     }
 
+    /* One slice of a bulk load: claims the key slot with a compare-and-swap, like the reference's concurrent put
+       (include/sampled_suffix_array.h:183-211 there), and asks for the table line a few samples ahead: the
+       table is gigabytes for a genome-sized text and every insertion is a cache miss. */
+    struct load_body {
+      sampled_suffix_array * s; const idx_t * ranks; const idx_t * poss; idx_t k; idx_t * inserted;
+      void operator() (idx_t t, idx_t nt) const {
+        const idx_t lo = k * t / nt, hi = k * (t + 1) / nt, mask = s->sz - 1;
+        ssa_entry * a = s->a;
+        idx_t mine = 0;
+        for (idx_t i = lo; i < hi; i++) {
+          if (i + 8 < hi) __builtin_prefetch(&a[ranks[i + 8] & mask], 1);
+          const idx_t rank = ranks[i];
+          for (idx_t h = rank & mask, probes = 0; ; h = (h + 1) & mask, probes++) {
+            check(probes < s->sz); /* table full */
+            idx_t seen = __sync_val_compare_and_swap(&a[h].rank, (idx_t)-1, rank);
+            if (seen == -1) { a[h].pos = poss[i]; mine++; break; }
+            if (seen == rank) break;
+          }
+        }
+        __sync_fetch_and_add(inserted, mine);
+      }
+    };
+
     /* fills the table from k samples (absolute ranks); any previous content is dropped */
     void load(idx_t sz_req, const idx_t * ranks, const idx_t * poss, idx_t k, mallocator & mem) {
       if (a) fini(mem);
       init(sz_req, mem);
-      for (idx_t i = 0; i < k; i++) put(ranks[i], poss[i]);
+      stat.start(ts_event_ssa_put);
+      idx_t inserted = 0;
+      load_body lb = { this, ranks, poss, k, &inserted };
+      on_threads(k, lb);
+      n = inserted;
+      stat.end(ts_event_ssa_put);
     }
   };
 

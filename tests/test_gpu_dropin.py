@@ -43,6 +43,9 @@ def test_own_simplest_example():
     ["--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1", "-m", "3.0", "2000000"],
     ["--generator", "nrand48", "--alpha_max", "z", "-t", "5000", "--ssa_n_samples", "300", "--build_gap_segment_sz", "77", "200000"],
     ["--stat_level", "1", "--mstat_level", "1", "--repeat", "2", "50000"],
+    ["--check", "2", "--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1", "300000"],  # the host's serial ibwt
+    # 2e8 symbols: host T -> device, 4 leaves, round trip decoded on the device
+    ["--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1", "-t", "50000000", "200000000"],
 ])
 def test_own_cli_round_trip(args):
     rc, out = run(need(os.path.join(OWN, "pmbwt")), *args)
@@ -66,3 +69,19 @@ def test_reference_cli_unmodified(args):
 def test_reference_tests_unmodified(prog, args):
     rc, out = run(need(os.path.join(REF, prog)), *args)
     assert rc == 0 and "NG" not in out, out[-2000:]
+
+
+def test_stat_table_credits_every_device_phase():
+    """pmbwt with stat_level 1 prints the reference's event table (include/util.h:93-98, 102-135 there): the rows the
+    reference fills on this path must be there with the right call counts -- 4 leaves, 3 merges -- and non-zero time."""
+    import re
+    rc, out = run(need(os.path.join(OWN, "pmbwt")), "--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1",
+                  "--stat_level", "1", "-t", "60000", "--check", "0", "200000")
+    assert rc == 0, out[-2000:]
+    rows = {m.group(1): (int(m.group(2)), int(m.group(3)))
+            for m in re.finditer(r"^\s*(\w+) :\s*(\d+) /\s*(\d+) =", out, re.M)}
+    want = {"bwt_leaf": 4, "bwt_sample_sa": 4, "bwt_count_alphabets": 3, "bwt_build_wavelet_matrix": 3, "bwt_build_gap": 3,
+            "gap_array_set_prefix_sum": 3, "bwt_merge_loop": 3, "bwt_resample_sa": 3, "pmbwt": 1, "ssa_put": 1}
+    for ev, calls in want.items():
+        assert ev in rows, (ev, sorted(rows))
+        assert rows[ev][1] == calls and rows[ev][0] > 0, (ev, rows[ev])

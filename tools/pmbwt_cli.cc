@@ -2,7 +2,8 @@
 //
 // Takes the flags of the reference's src/pmbwt.cc (:148-177) with the same
 // meaning, generates or reads a text, builds its BWT with bwt::pmbwt and, with
-// --check 1 (the default), inverts it on the host and compares (src/pmbwt.cc:64-81).
+// --check 1 (the default), inverts it and compares (src/pmbwt.cc:64-81): on the device, cut at the samples;
+// --check 2 takes the reference's serial walk on the host (init_extra + ibwt).
 //
 // Differences from the reference's program, on purpose:
 //   --generator splitmix (default) draws symbols from a splitmix64 stream;
@@ -177,7 +178,13 @@ int main(int argc, char ** argv) {
     printf(" stat_level = %d\n mstat_level = %d\n assert_level = %d\n seed = %ld\n", c.stat_level, c.mstat_level,
            opt.assert_level, (long)c.seed);
     bwt::bwt t = bwt::pmbwt(T, n, L, c.stat_level, mem, opt);
-    if (c.check) {
+    if (c.check == 1 && t.dev) {
+      // decoded on the device from the block that is still there: one LF walk per sample instead of one serial walk
+      printf("checking result ... ");
+      fflush(stdout);
+      ok = (t.round_trip_mismatches() == 0);
+      printf(ok ? "OK\n" : "NG\n");
+    } else if (c.check) {
       bwt::alpha_t * I = new bwt::alpha_t[n];
       memset(I, 0xA5, n);
       printf("checking result ... ");
