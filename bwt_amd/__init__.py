@@ -85,6 +85,18 @@ def lib():
         "bwt_hip_test_sort_u32": [vp, _u32p, _u32p, i64, i32, i32],
         "bwt_hip_test_scan_u32": [vp, _u32p, i64, i32],
     }
+    sig.update({
+        "bwt_hip_rccl_unique_id": [_u8p],
+        "bwt_hip_transport_rccl": [vp, _u8p, i32, i32, C.POINTER(vp)],
+        "bwt_hip_transport_local": [i32, C.POINTER(vp)],
+        "bwt_hip_dist_pmbwt": [vp, vp, i64, i64, i64, C.POINTER(vp)],
+        "bwt_hip_slice_info": [vp, _i64p, _i64p, _i64p, _i64p, _i64p],
+        "bwt_hip_slice_L_device": [vp, C.POINTER(vp)],
+        "bwt_hip_slice_get_L": [vp, vp, _u8p],
+        "bwt_hip_slice_get_samples": [vp, vp, _i64p, _i64p, i64],
+        "bwt_hip_pmbwt_multi": [C.POINTER(i32), i32, _u8p, i64, i64, i64, i64, _u8p, _i64p, _i64p, _i64p, _i64p, i64, _i64p,
+                                C.POINTER(i32)],
+    })
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
@@ -97,6 +109,10 @@ def lib():
     L.bwt_hip_host_alloc.restype = i32
     L.bwt_hip_host_free.argtypes = [vp]
     L.bwt_hip_host_free.restype = None
+    L.bwt_hip_transport_free.argtypes = [vp]
+    L.bwt_hip_transport_free.restype = None
+    L.bwt_hip_slice_free.argtypes = [vp]
+    L.bwt_hip_slice_free.restype = None
     L.bwt_hip_stream.argtypes = [vp]
     L.bwt_hip_stream.restype = vp
     _lib = L
@@ -131,6 +147,75 @@ class HostBuffer:
             self.close()
         except Exception:
             pass
+
+
+def pmbwt_multi(devices, T, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz=0):
+    """bwt::pmbwt of the host text T over the listed GPUs (one thread and context per entry; an entry may repeat).
+    Returns (L, s_rank, e_rank, sample ranks, sample positions, GPUs used)."""
+    T = np.ascontiguousarray(T, dtype=np.uint8)
+    n = len(T)
+    dev = (C.c_int * len(devices))(*devices)
+    L = np.empty(n, dtype=np.uint8)
+    cap = min(n, max(1, ssa_n_samples))
+    sr, sp = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64)
+    s_rank, e_rank, ns, used = C.c_int64(-1), C.c_int64(-1), C.c_int64(0), C.c_int(0)
+    _chk(lib().bwt_hip_pmbwt_multi(dev, len(devices), _p(T, _u8p), n, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz,
+                                   _p(L, _u8p), C.byref(s_rank), C.byref(e_rank), _p(sr, _i64p), _p(sp, _i64p), cap,
+                                   C.byref(ns), C.byref(used)))
+    k = min(ns.value, cap)
+    return L, s_rank.value, e_rank.value, sr[:k], sp[:k], used.value
+
+
+class Transport:
+    """A bwt_hip_transport handle (one rank's end)."""
+
+    def __init__(self, h):
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().bwt_hip_transport_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        _chk(lib().bwt_hip_rccl_unique_id(_p(buf, _u8p)))
+        return buf
+
+    @staticmethod
+    def rccl(ctx, unique_id, rank, world):
+        h = C.c_void_p()
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        _chk(lib().bwt_hip_transport_rccl(ctx._h, _p(uid, _u8p), rank, world, C.byref(h)))
+        return Transport(h)
+
+
+class Slice:
+    """This rank's slice of a block spread over the ranks of a multi-GPU build."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+        v = [C.c_int64() for _ in range(5)]
+        _chk(lib().bwt_hip_slice_info(h, *[C.byref(x) for x in v]))
+        self.first, self.size, self.s_rank, self.e_rank, self.n_samples = [x.value for x in v]
+
+    @property
+    def L(self):
+        out = np.empty(self.size, dtype=np.uint8)
+        _chk(lib().bwt_hip_slice_get_L(self.ctx._h, self._h, _p(out, _u8p)))
+        return out
+
+    def samples(self):
+        r = np.empty(self.n_samples, dtype=np.int64)
+        p = np.empty(self.n_samples, dtype=np.int64)
+        _chk(lib().bwt_hip_slice_get_samples(self.ctx._h, self._h, _p(r, _i64p), _p(p, _i64p), self.n_samples))
+        return r, p
+
+    def free(self):
+        if self._h:
+            lib().bwt_hip_slice_free(self._h)
+            self._h = None
 
 
 def dist_bounds(m, parts):
@@ -207,6 +292,12 @@ class Context:
         h = C.c_void_p()
         _chk(lib().bwt_hip_pmbwt(self._h, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
         return self._blk(h)
+
+    def dist_pmbwt(self, transport, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz=0):
+        """bwt::pmbwt over the transport's ranks; every rank calls it.  Returns this rank's Slice."""
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_dist_pmbwt(self._h, transport._h, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
+        return Slice(self, h)
 
     def upload_block(self, a, b, L, s_rank, e_rank, samp_rank, samp_pos):
         L = np.ascontiguousarray(L, dtype=np.uint8)

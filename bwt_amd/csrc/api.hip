@@ -9,9 +9,6 @@
 
 using namespace bwtamd;
 
-struct bwt_hip_ctx {
-  Ctx c;
-};
 struct bwt_hip_block {
   Block b;
 };
@@ -19,6 +16,10 @@ struct bwt_hip_block {
 static thread_local std::string g_last_error;
 
 const char *bwt_hip_last_error(void) { return g_last_error.c_str(); }
+namespace bwtamd {
+void set_last_error(const char *msg) { g_last_error = msg; }
+Block *build_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg);
+}
 
 #define API_BEGIN try {
 #define API_END                                  \
@@ -239,6 +240,7 @@ static Block *do_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg) {
   std::unique_ptr<Block> r(do_rec(c, mid, b, th, ns, seg));
   return do_merge(c, l.release(), r.release(), ns, seg);
 }
+Block *bwtamd::build_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg) { return do_rec(c, a, b, th, ns, seg); }
 
 int bwt_hip_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ns, bwt_hip_block **out) {
   API_BEGIN

@@ -1,0 +1,764 @@
+// bwt::pmbwt over several GPUs (declared in include/bwt_hip.h, "the whole build over several GPUs").
+//
+// The recursion tree of bwt_rec (reference include/bwt.h:854-865: split at (a+b)/2) is cut at depth
+// log2(world); rank k builds subtree k on its own GPU.  A block of the tree that spans q ranks stays spread
+// over them as q slices of its L (rank ranges), its samples and special ranks on the first of them.  A merge
+// of two such blocks (include/bwt.h:791-847) runs on all G = 2q ranks:
+//   1. every rank receives the left block's L (each holder sends its slice to all others) and builds the
+//      left rank structure;
+//   2. the right block's text positions are split evenly; every rank runs the LF chains of its share
+//      (g_j depends on the left block and the text only, and every rank holds the text);
+//   3. the merge is cut by left rank into G parts (partition_bounds): one all-to-all moves every g value
+//      to the rank that owns its part, a second one the right symbols that part interleaves;
+//   4. every rank builds its part's prefix sums and writes its slice of the merged L;
+//   5. both sample sets go to every rank, each places the samples whose new rank it knows, the group's
+//      first rank collects them.
+// Same tree, same rules: the slices concatenated are the L of the single-GPU build, bit for bit.
+//
+// Ranks move device memory through a bwt_hip_transport (one primitive: a batch of sends and receives).  Two
+// ship here: RCCL (a process or thread per GPU, ncclSend/ncclRecv over xGMI) and an in-process one (a thread
+// per GPU, peer copies), which bwt_hip_pmbwt_multi uses.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "../../include/bwt_hip.h"
+#include "internal.h"
+
+namespace bwtamd {
+
+// ---------------------------------------------------------------------------
+// the tree
+// ---------------------------------------------------------------------------
+static void split_ranges(i64 a, i64 b, int depth, std::vector<std::pair<i64, i64>> &out) {
+  if (depth == 0) {
+    out.push_back({a, b});
+    return;
+  }
+  const i64 mid = (a + b) / 2;
+  split_ranges(a, mid, depth - 1, out);
+  split_ranges(mid, b, depth - 1, out);
+}
+
+// Does bwt_rec with this threshold split every range down to depth `depth`?  (Then the tree has 2^depth
+// subtrees there, one per rank.)
+static bool tree_reaches(i64 n, i64 th, int depth) {
+  if (depth == 0) return true;
+  std::vector<std::pair<i64, i64>> parents;
+  split_ranges(0, n, depth - 1, parents);
+  for (auto &r : parents)
+    if (r.second - r.first <= th || r.second - r.first < 2) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+__global__ void k_add_u32(u32 *__restrict__ acc, const u32 *__restrict__ x, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += x[i];
+}
+__global__ void k_u32_to_i64(const u32 *__restrict__ in, u64 n, i64 *__restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (i64)in[i];
+}
+__global__ void k_i64_to_u32(const i64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (u32)in[i];
+}
+__global__ void k_abs_ranks(const u32 *__restrict__ rel, u64 n, u32 a, u32 *__restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rel[i] + a;
+}
+
+template <class K, class... A>
+static void launch1d(Ctx &c, K kernel, u64 n, A... args) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(kernel, dim3(ceil_div(n, 256)), dim3(256), 0, c.stream, args...);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// a block spread over ranks
+// ---------------------------------------------------------------------------
+struct DistBlock {
+  i64 a = 0, b = 0;
+  int first = 0, q = 1;       // held by the ranks first .. first+q-1
+  std::vector<i64> sizes;     // symbols of every holder's slice
+  DBuf<u8> L;                 // this rank's slice
+  i64 s_rank = -1, e_rank = -1;  // absolute; on rank `first` only
+  DBuf<u32> samp_rank, samp_pos; // absolute ranks, positions; on rank `first` only
+  i64 n_samp = 0;
+};
+
+struct Group {
+  bwt_hip_transport *t;
+  Ctx &c;
+  int first, G, me, k;  // ranks first .. first+G-1; k = me - first
+
+  void exchange(std::vector<bwt_hip_p2p> &ops) {
+    c.sync();  // what is sent has been written; what is received into is no longer read
+    std::vector<bwt_hip_p2p> live;
+    for (auto &o : ops)
+      if (o.bytes > 0) live.push_back(o);
+    if (live.empty()) return;
+    const int rc = t->exchange(t->self, (int)live.size(), live.data());
+    if (rc != 0) fail(rc, "transport: exchange of %zu transfers failed on rank %d", live.size(), me);
+  }
+
+  // out[j * count + i] = value i of group member j
+  std::vector<i64> all_gather(const std::vector<i64> &mine) {
+    const size_t cnt = mine.size();
+    DBuf<i64> d(c, cnt * (size_t)G);
+    HIP_CHECK(hipMemcpyAsync(d.get() + cnt * (size_t)k, mine.data(), cnt * 8, hipMemcpyHostToDevice, c.stream));
+    std::vector<bwt_hip_p2p> ops;
+    for (int j = 0; j < G; j++)
+      if (j != k) ops.push_back({first + j, 1, d.get() + cnt * (size_t)k, (i64)cnt * 8});
+    for (int j = 0; j < G; j++)
+      if (j != k) ops.push_back({first + j, 0, d.get() + cnt * (size_t)j, (i64)cnt * 8});
+    exchange(ops);
+    std::vector<i64> out(cnt * (size_t)G);
+    HIP_CHECK(hipMemcpyAsync(out.data(), d.get(), out.size() * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return out;
+  }
+
+  // piece j of `send` (send_bytes[j], consecutive) goes to member j; recv_bytes[j] arrive from member j, consecutive in recv
+  void all_to_all(const u8 *send, const std::vector<i64> &send_bytes, u8 *recv, const std::vector<i64> &recv_bytes) {
+    std::vector<bwt_hip_p2p> ops;
+    i64 so = 0, ro = 0, my_so = 0, my_ro = 0;
+    for (int j = 0; j < G; j++) {
+      if (j == k) my_so = so;
+      else ops.push_back({first + j, 1, const_cast<u8 *>(send) + so, send_bytes[(size_t)j]});
+      so += send_bytes[(size_t)j];
+    }
+    for (int j = 0; j < G; j++) {
+      if (j == k) my_ro = ro;
+      else ops.push_back({first + j, 0, recv + ro, recv_bytes[(size_t)j]});
+      ro += recv_bytes[(size_t)j];
+    }
+    if (send_bytes[(size_t)k] != recv_bytes[(size_t)k]) fail(BWT_HIP_EINTERNAL, "all-to-all: own piece %ld != %ld", (long)send_bytes[(size_t)k], (long)recv_bytes[(size_t)k]);
+    if (send_bytes[(size_t)k] > 0)
+      HIP_CHECK(hipMemcpyAsync(recv + my_ro, send + my_so, (size_t)send_bytes[(size_t)k], hipMemcpyDeviceToDevice, c.stream));
+    exchange(ops);
+  }
+
+  // buf (bytes) on member `root` reaches every member
+  void broadcast(void *buf, i64 bytes, int root) {
+    std::vector<bwt_hip_p2p> ops;
+    if (k == root) {
+      for (int j = 0; j < G; j++)
+        if (j != k) ops.push_back({first + j, 1, buf, bytes});
+    } else {
+      ops.push_back({first + root, 0, buf, bytes});
+    }
+    exchange(ops);
+  }
+
+  // acc[0:n) on member 0 += the arrays of all other members (whose entries are zero where they placed nothing)
+  void sum_to_first(u32 *acc, u64 n) {
+    if (n == 0) return;
+    if (k != 0) {
+      std::vector<bwt_hip_p2p> ops{{first, 1, acc, (i64)n * 4}};
+      exchange(ops);
+      return;
+    }
+    DBuf<u32> in(c, (size_t)n * (size_t)(G - 1));
+    std::vector<bwt_hip_p2p> ops;
+    for (int j = 1; j < G; j++) ops.push_back({first + j, 0, in.get() + (size_t)n * (size_t)(j - 1), (i64)n * 4});
+    exchange(ops);
+    for (int j = 1; j < G; j++) launch1d(c, k_add_u32, n, acc, (const u32 *)(in.get() + (size_t)n * (size_t)(j - 1)), n);
+  }
+};
+
+static i64 overlap(i64 lo0, i64 hi0, i64 lo1, i64 hi1) {
+  const i64 lo = lo0 > lo1 ? lo0 : lo1, hi = hi0 < hi1 ? hi0 : hi1;
+  return hi > lo ? hi - lo : 0;
+}
+
+// Merges the block held by the group's first half (left) with the one held by its second half (right); every
+// member calls this with the block it holds a slice of.  Consumes blk.
+static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock> blk, i64 ns_req, i64 seg) {
+  Ctx &c = g.c;
+  const int G = g.G, q = G / 2, k = g.k;
+  const int mine_at = g.me - blk->first;
+  std::vector<i64> meta = g.all_gather({blk->a, blk->b, blk->s_rank, blk->e_rank, blk->n_samp, blk->sizes[(size_t)mine_at]});
+  auto M = [&](int j, int f) { return meta[(size_t)j * 6 + (size_t)f]; };
+  const i64 a = M(0, 0), cpos = M(0, 1), b = M(q, 1);
+  if (M(q, 0) != cpos) fail(BWT_HIP_EINTERNAL, "blocks are not adjacent: [%ld,%ld) and [%ld,%ld)", (long)a, (long)cpos, (long)M(q, 0), (long)b);
+  const i64 m = cpos - a, r = b - cpos;
+  std::vector<i64> loff(1, 0), roff(1, 0);
+  for (int j = 0; j < q; j++) loff.push_back(loff.back() + M(j, 5));
+  for (int j = 0; j < q; j++) roff.push_back(roff.back() + M(q + j, 5));
+  if (loff.back() != m || roff.back() != r) fail(BWT_HIP_EINTERNAL, "slice sizes do not add up to the blocks");
+  const i64 s_rank_l = M(0, 2), e_rank_l = M(0, 3), nl = M(0, 4), nr = M(q, 4);
+
+  // 1. the left block's L on every member
+  std::unique_ptr<Block> lb(new Block());
+  lb->a = a;
+  lb->b = cpos;
+  lb->s_rank = s_rank_l - a;
+  lb->e_rank = e_rank_l - a;
+  lb->L = DBuf<u8>(c, (size_t)m);
+  {
+    std::vector<bwt_hip_p2p> ops;
+    if (k < q) {
+      HIP_CHECK(hipMemcpyAsync(lb->L.get() + loff[(size_t)k], blk->L.get(), (size_t)M(k, 5), hipMemcpyDeviceToDevice, c.stream));
+      for (int j = 0; j < G; j++)
+        if (j != k) ops.push_back({g.first + j, 1, blk->L.get(), M(k, 5)});
+    }
+    for (int j = 0; j < q; j++)
+      if (j != k) ops.push_back({g.first + j, 0, lb->L.get() + loff[(size_t)j], M(j, 5)});
+    g.exchange(ops);
+  }
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (cpos - 1), 1, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  lb->e_char = *(u8 *)c.h_scalars;
+
+  // 2. LF chains of this member's share of the right positions
+  const i64 p_lo = cpos + (i64)k * r / G, p_hi = cpos + (i64)(k + 1) * r / G;
+  DBuf<u32> gt(c, (size_t)(p_hi - p_lo > 0 ? p_hi - p_lo : 1));
+  if (p_hi > p_lo) {
+    DBuf<u32> g0;
+    ChainLayout lay = run_chains(c, *lb, p_lo, p_hi, seg, g0);
+    chains_text_order(c, lay, g0.get(), gt.get());
+  }
+  lb->wm = WaveletDev();  // the rank structure is not needed any more; L is (step 4)
+
+  // 3. every g value to the member that owns its part, then the right symbols each part interleaves
+  const i64 cnt = p_hi - p_lo;
+  DBuf<u32> g_parts(c, (size_t)(cnt > 0 ? cnt : 1));
+  std::vector<i64> counts((size_t)G, 0);
+  partition_by_left_rank(c, gt.get(), (u64)cnt, (u64)m, (u32)G, g_parts.get(), counts.data());
+  std::vector<i64> table = g.all_gather(counts);  // table[src * G + part]
+  std::vector<i64> R((size_t)G, 0), rb(1, 0), send_b((size_t)G), recv_b((size_t)G);
+  for (int d = 0; d < G; d++)
+    for (int s = 0; s < G; s++) R[(size_t)d] += table[(size_t)s * (size_t)G + (size_t)d];
+  for (int d = 0; d < G; d++) rb.push_back(rb.back() + R[(size_t)d]);
+  if (rb.back() != r) fail(BWT_HIP_EINTERNAL, "parts hold %ld of %ld right suffixes", (long)rb.back(), (long)r);
+  const i64 rn = R[(size_t)k];
+  DBuf<u32> g_in(c, (size_t)(rn > 0 ? rn : 1));
+  for (int j = 0; j < G; j++) {
+    send_b[(size_t)j] = counts[(size_t)j] * 4;
+    recv_b[(size_t)j] = table[(size_t)j * (size_t)G + (size_t)k] * 4;
+  }
+  g.all_to_all((const u8 *)g_parts.get(), send_b, (u8 *)g_in.get(), recv_b);
+  DBuf<u8> rL(c, (size_t)(rn > 0 ? rn : 1));
+  for (int d = 0; d < G; d++) {
+    send_b[(size_t)d] = k >= q ? overlap(roff[(size_t)(k - q)], roff[(size_t)(k - q + 1)], rb[(size_t)d], rb[(size_t)d + 1]) : 0;
+    recv_b[(size_t)d] = d >= q ? overlap(roff[(size_t)(d - q)], roff[(size_t)(d - q + 1)], rb[(size_t)k], rb[(size_t)k + 1]) : 0;
+  }
+  g.all_to_all(k >= q ? blk->L.get() : (const u8 *)rL.get(), send_b, rL.get(), recv_b);
+
+  // 4. this part's slice of the merged block
+  std::vector<i64> lo((size_t)G + 1);
+  partition_bounds((u64)m, (u32)G, lo.data());
+  auto clampm = [&](i64 v) { return v < m ? v : m; };
+  const i64 i_lo = clampm(lo[(size_t)k]), i_hi = clampm(lo[(size_t)k + 1]), mL = i_hi - i_lo;
+  std::unique_ptr<DistBlock> out(new DistBlock());
+  out->a = a;
+  out->b = b;
+  out->first = g.first;
+  out->q = G;
+  for (int d = 0; d < G; d++) out->sizes.push_back(clampm(lo[(size_t)d + 1]) - clampm(lo[(size_t)d]) + R[(size_t)d]);
+  out->L = DBuf<u8>(c, (size_t)(mL + rn > 0 ? mL + rn : 1));
+  DBuf<u32> S(c, (size_t)mL + 1);
+  {
+    DBuf<u32> scratch(c, (size_t)(rn > 0 ? rn : 1));
+    gap_prefix(c, g_in.get(), scratch.get(), (u64)rn, (u64)mL, S.get());
+    merge_symbols(c, lb->L.get() + i_lo, (u64)mL, rL.get(), (u64)rn, S.get(), out->L.get());
+  }
+
+  // 5. samples: both sets to every member (32-bit words on the wire), each places what it can, the first collects
+  DBuf<u32> w_lr(c, (size_t)(nl ? nl : 1)), w_lp(c, (size_t)(nl ? nl : 1)), w_rr(c, (size_t)(nr ? nr : 1)), w_rp(c, (size_t)(nr ? nr : 1));
+  if (k == 0) {
+    HIP_CHECK(hipMemcpyAsync(w_lr.get(), blk->samp_rank.get(), (size_t)nl * 4, hipMemcpyDeviceToDevice, c.stream));
+    HIP_CHECK(hipMemcpyAsync(w_lp.get(), blk->samp_pos.get(), (size_t)nl * 4, hipMemcpyDeviceToDevice, c.stream));
+  }
+  if (k == q) {
+    HIP_CHECK(hipMemcpyAsync(w_rr.get(), blk->samp_rank.get(), (size_t)nr * 4, hipMemcpyDeviceToDevice, c.stream));
+    HIP_CHECK(hipMemcpyAsync(w_rp.get(), blk->samp_pos.get(), (size_t)nr * 4, hipMemcpyDeviceToDevice, c.stream));
+  }
+  g.broadcast(w_lr.get(), nl * 4, 0);
+  g.broadcast(w_lp.get(), nl * 4, 0);
+  g.broadcast(w_rr.get(), nr * 4, q);
+  g.broadcast(w_rp.get(), nr * 4, q);
+  const u64 nn = (u64)(nl + nr);
+  const i64 ns_out = ns_req < m + r ? ns_req : m + r;
+  u64 kept = nn;
+  if (nn >= 1) {
+    const u64 t = 1 + (nn > 1 ? ((nn - 1) * (u64)(ns_out - 1)) / (nn - 1) : 0);  // as k_resample selects: A = ns_out-1, B = nn-1
+    kept = t < nn ? t : nn;
+  }
+  DBuf<u32> o_rank(c, (size_t)(kept ? kept : 1)), o_pos(c, (size_t)(kept ? kept : 1));
+  {
+    DBuf<i64> lr(c, (size_t)(nl ? nl : 1)), lp(c, (size_t)(nl ? nl : 1)), rr(c, (size_t)(nr ? nr : 1)), rp(c, (size_t)(nr ? nr : 1));
+    DBuf<i64> orank(c, (size_t)(kept ? kept : 1)), opos(c, (size_t)(kept ? kept : 1));
+    launch1d(c, k_u32_to_i64, (u64)nl, (const u32 *)w_lr.get(), (u64)nl, lr.get());
+    launch1d(c, k_u32_to_i64, (u64)nl, (const u32 *)w_lp.get(), (u64)nl, lp.get());
+    launch1d(c, k_u32_to_i64, (u64)nr, (const u32 *)w_rr.get(), (u64)nr, rr.get());
+    launch1d(c, k_u32_to_i64, (u64)nr, (const u32 *)w_rp.get(), (u64)nr, rp.get());
+    HIP_CHECK(hipMemsetAsync(orank.get(), 0, (size_t)(kept ? kept : 1) * 8, c.stream));
+    HIP_CHECK(hipMemsetAsync(opos.get(), 0, (size_t)(kept ? kept : 1) * 8, c.stream));
+    ResamplePart P;
+    P.l_rank = lr.get();
+    P.l_pos = lp.get();
+    P.nl = (u64)nl;
+    P.r_rank = rr.get();
+    P.r_pos = rp.get();
+    P.nr = (u64)nr;
+    P.a = a;
+    P.cc = cpos;
+    P.A = (u64)(ns_out - 1);
+    P.B = nn ? nn - 1 : 0;
+    P.S_local = S.get();
+    P.i_lo = (u64)i_lo;
+    P.i_hi = (u64)i_hi;
+    P.right_before = (u64)rb[(size_t)k];
+    P.g_local = gt.get();
+    P.p_lo = (u64)p_lo;
+    P.p_hi = (u64)p_hi;
+    P.o_rank = orank.get();
+    P.o_pos = opos.get();
+    resample_part(c, P);
+    launch1d(c, k_i64_to_u32, kept, (const i64 *)orank.get(), kept, o_rank.get());
+    launch1d(c, k_i64_to_u32, kept, (const i64 *)opos.get(), kept, o_pos.get());
+    c.sync();  // the temporaries die here
+  }
+  g.sum_to_first(o_rank.get(), kept);
+  g.sum_to_first(o_pos.get(), kept);
+  if (k == 0) {
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, o_rank.get(), 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 1, o_rank.get() + (kept - 1), 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 2, o_pos.get() + (kept - 1), 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    if ((i64)c.h_scalars[2] != b - 1)
+      fail(BWT_HIP_EINTERNAL, "merge [%ld,%ld): last sample is at %u, not at b-1", (long)a, (long)b, c.h_scalars[2]);
+    out->s_rank = (i64)c.h_scalars[0];
+    out->e_rank = (i64)c.h_scalars[1];
+    out->samp_rank = std::move(o_rank);
+    out->samp_pos = std::move(o_pos);
+    out->n_samp = (i64)kept;
+  }
+  c.sync();
+  return out;
+}
+
+static std::unique_ptr<DistBlock> dist_build(Ctx &c, bwt_hip_transport *t, i64 th, i64 ns, i64 seg) {
+  const int world = t->world, me = t->rank;
+  if (world < 1 || (world & (world - 1)) || me < 0 || me >= world) fail(BWT_HIP_EINVAL, "rank %d of %d: the number of ranks must be a power of two", me, world);
+  if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
+  int depth = 0;
+  while ((1 << depth) < world) depth++;
+  if (!tree_reaches(c.n, th, depth))
+    fail(BWT_HIP_EINVAL, "bwt_rec_threshold %ld leaves fewer than %d subtrees at depth %d of a text of %ld symbols", (long)th, world, depth, (long)c.n);
+  std::vector<std::pair<i64, i64>> ranges;
+  split_ranges(0, c.n, depth, ranges);
+  const i64 a = ranges[(size_t)me].first, b = ranges[(size_t)me].second;
+  std::unique_ptr<Block> own(build_rec(c, a, b, th, ns, seg));
+  std::unique_ptr<DistBlock> blk(new DistBlock());
+  blk->a = a;
+  blk->b = b;
+  blk->first = me;
+  blk->q = 1;
+  blk->sizes.push_back(b - a);
+  blk->s_rank = a + own->s_rank;
+  blk->e_rank = a + own->e_rank;
+  blk->n_samp = own->n_samp;
+  blk->samp_rank = DBuf<u32>(c, (size_t)(own->n_samp ? own->n_samp : 1));
+  launch1d(c, k_abs_ranks, (u64)own->n_samp, (const u32 *)own->samp_rank.get(), (u64)own->n_samp, (u32)a, blk->samp_rank.get());
+  blk->samp_pos = std::move(own->samp_pos);
+  blk->L = std::move(own->L);
+  c.sync();
+  own.reset();
+  for (int G = 2; G <= world; G *= 2) {
+    Group g{t, c, (me / G) * G, G, me, me % G};
+    blk = dist_merge(g, std::move(blk), ns, seg);
+  }
+  return blk;
+}
+
+// ---------------------------------------------------------------------------
+// transport: ranks that are threads of one process
+// ---------------------------------------------------------------------------
+struct LocalHub {
+  struct Post {
+    const void *ptr;
+    i64 bytes;
+    int dev;
+    bool done;
+  };
+  std::mutex mu;
+  std::condition_variable cv;
+  int world, refs;
+  std::vector<std::deque<Post *>> box;  // box[src * world + dst]: what src has offered to dst, oldest first
+  bool broken = false;                  // a member failed: nobody waits any longer
+};
+
+struct LocalEnd {
+  bwt_hip_transport iface;
+  LocalHub *hub;
+  hipStream_t stream = nullptr;
+  int stream_dev = -1;
+};
+
+static int local_exchange(void *self, int n_ops, const bwt_hip_p2p *ops) {
+  LocalEnd *e = (LocalEnd *)self;
+  LocalHub *h = e->hub;
+  const int me = e->iface.rank;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return BWT_HIP_EINTERNAL;
+  if (!e->stream || e->stream_dev != dev) {
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return BWT_HIP_EINTERNAL;
+    e->stream_dev = dev;
+  }
+  std::vector<LocalHub::Post *> mine;
+  int rc = 0;
+  {
+    std::unique_lock<std::mutex> lock(h->mu);
+    for (int i = 0; i < n_ops; i++) {
+      if (!ops[i].is_send) continue;
+      if (ops[i].peer < 0 || ops[i].peer >= h->world || ops[i].peer == me) return BWT_HIP_EINVAL;
+      LocalHub::Post *p = new LocalHub::Post{ops[i].buf, ops[i].bytes, dev, false};
+      h->box[(size_t)me * (size_t)h->world + (size_t)ops[i].peer].push_back(p);
+      mine.push_back(p);
+    }
+    h->cv.notify_all();
+    for (int i = 0; i < n_ops && rc == 0; i++) {
+      if (ops[i].is_send) continue;
+      if (ops[i].peer < 0 || ops[i].peer >= h->world || ops[i].peer == me) {
+        rc = BWT_HIP_EINVAL;
+        break;
+      }
+      auto &q = h->box[(size_t)ops[i].peer * (size_t)h->world + (size_t)me];
+      h->cv.wait(lock, [&] { return !q.empty() || h->broken; });
+      if (h->broken) {
+        rc = BWT_HIP_EINTERNAL;
+        break;
+      }
+      LocalHub::Post *p = q.front();
+      q.pop_front();
+      if (p->bytes != ops[i].bytes) {
+        rc = BWT_HIP_EINTERNAL;
+      } else {
+        lock.unlock();
+        hipError_t he = p->dev == dev ? hipMemcpyAsync(ops[i].buf, p->ptr, (size_t)p->bytes, hipMemcpyDeviceToDevice, e->stream)
+                                      : hipMemcpyPeerAsync(ops[i].buf, dev, p->ptr, p->dev, (size_t)p->bytes, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        lock.lock();
+        if (he != hipSuccess) rc = (int)he;
+      }
+      p->done = true;
+      h->cv.notify_all();
+    }
+    if (rc != 0) {
+      h->broken = true;
+      h->cv.notify_all();
+    }
+    h->cv.wait(lock, [&] {
+      if (h->broken) return true;
+      for (auto *p : mine)
+        if (!p->done) return false;
+      return true;
+    });
+    if (h->broken && rc == 0) rc = BWT_HIP_EINTERNAL;
+    if (!h->broken)
+      for (auto *p : mine) delete p;  // (after a failure the posts may still sit in a mailbox: leaked on purpose)
+  }
+  return rc;
+}
+
+static void local_destroy(void *self) {
+  LocalEnd *e = (LocalEnd *)self;
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  LocalHub *h = e->hub;
+  bool last;
+  {
+    std::lock_guard<std::mutex> lock(h->mu);
+    last = --h->refs == 0;
+  }
+  if (last) delete h;
+  delete e;
+}
+
+// ---------------------------------------------------------------------------
+// transport: RCCL
+// ---------------------------------------------------------------------------
+struct Id128 {  // ncclUniqueId: 128 opaque bytes, passed by value
+  char b[128];
+};
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // a copy the process already holds (for example the one PyTorch brought) is taken before a second one is loaded
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+      if (api.lib) break;
+    }
+    if (!api.lib)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+      }
+    if (!api.lib) return;
+    auto sym = [&](const char *s) { return dlsym(api.lib, s); };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  });
+  if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+    fail(BWT_HIP_EINTERNAL, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  return api;
+}
+
+static void rccl_ok(int rc, const char *what) {
+  if (rc != 0) fail(BWT_HIP_EINTERNAL, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+}
+
+struct RcclEnd {
+  bwt_hip_transport iface;
+  void *comm = nullptr;
+  hipStream_t stream = nullptr;  // the context's stream: transfers queue behind the kernels that made the data
+  int device = 0;
+};
+
+static int rccl_exchange(void *self, int n_ops, const bwt_hip_p2p *ops) {
+  RcclEnd *e = (RcclEnd *)self;
+  try {
+    RcclApi &api = rccl();
+    constexpr int NCCL_UINT8 = 1;  // ncclUint8 / ncclChar share the size; value of ncclUint8 in rccl.h
+    rccl_ok(api.GroupStart(), "ncclGroupStart");
+    for (int i = 0; i < n_ops; i++) {
+      if (ops[i].is_send) rccl_ok(api.Send(ops[i].buf, (size_t)ops[i].bytes, NCCL_UINT8, ops[i].peer, e->comm, e->stream), "ncclSend");
+      else rccl_ok(api.Recv(ops[i].buf, (size_t)ops[i].bytes, NCCL_UINT8, ops[i].peer, e->comm, e->stream), "ncclRecv");
+    }
+    rccl_ok(api.GroupEnd(), "ncclGroupEnd");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  } catch (const Error &err) {
+    fprintf(stderr, "bwt_hip RCCL transport: %s\n", err.what());
+    return err.code ? err.code : BWT_HIP_EINTERNAL;
+  }
+  return 0;
+}
+
+static void rccl_destroy(void *self) {
+  RcclEnd *e = (RcclEnd *)self;
+  if (e->comm) (void)rccl().CommDestroy(e->comm);
+  delete e;
+}
+
+struct Slice {
+  std::unique_ptr<DistBlock> d;
+  int rank = 0;
+  i64 first = 0;
+};
+
+}  // namespace bwtamd
+
+using namespace bwtamd;
+
+// ---------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------
+#define DIST_BEGIN try {
+#define DIST_END                                   \
+  }                                                \
+  catch (const Error &e) {                         \
+    set_last_error(e.what());             \
+    return e.code ? e.code : BWT_HIP_EINTERNAL;    \
+  }                                                \
+  catch (const std::exception &e) {                \
+    set_last_error(e.what());             \
+    return BWT_HIP_EINTERNAL;                      \
+  }                                                \
+  return 0;
+
+int bwt_hip_transport_local(int world, bwt_hip_transport **out) {
+  DIST_BEGIN
+  if (world < 1 || world > 256 || !out) fail(BWT_HIP_EINVAL, "invalid argument: 1 <= world <= 256, out");
+  LocalHub *h = new LocalHub();
+  h->world = world;
+  h->refs = world;
+  h->box.resize((size_t)world * (size_t)world);
+  for (int k = 0; k < world; k++) {
+    LocalEnd *e = new LocalEnd();
+    e->hub = h;
+    e->iface = bwt_hip_transport{e, k, world, local_exchange, local_destroy};
+    out[k] = &e->iface;
+  }
+  DIST_END
+}
+
+int bwt_hip_rccl_unique_id(uint8_t id[128]) {
+  DIST_BEGIN
+  if (!id) fail(BWT_HIP_EINVAL, "invalid argument: id");
+  rccl_ok(rccl().GetUniqueId(id), "ncclGetUniqueId");
+  DIST_END
+}
+
+int bwt_hip_transport_rccl(bwt_hip_ctx *ctx, const uint8_t id[128], int rank, int world, bwt_hip_transport **out) {
+  DIST_BEGIN
+  if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) fail(BWT_HIP_EINVAL, "invalid argument: ctx, id, out, 0 <= rank < world");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  std::unique_ptr<RcclEnd> e(new RcclEnd());
+  Id128 uid;
+  ::memcpy(uid.b, id, 128);
+  rccl_ok(rccl().CommInitRank(&e->comm, world, uid, rank), "ncclCommInitRank");
+  e->stream = c.stream;
+  e->device = c.device;
+  e->iface = bwt_hip_transport{e.get(), rank, world, rccl_exchange, rccl_destroy};
+  *out = &e.release()->iface;
+  DIST_END
+}
+
+void bwt_hip_transport_free(bwt_hip_transport *t) {
+  if (t && t->destroy) t->destroy(t->self);
+}
+
+int bwt_hip_dist_pmbwt(bwt_hip_ctx *ctx, bwt_hip_transport *t, int64_t th, int64_t ns, int64_t seg, bwt_hip_slice **out) {
+  DIST_BEGIN
+  if (!ctx || !t || !out || !t->exchange) fail(BWT_HIP_EINVAL, "invalid argument: ctx, transport, out");
+  if (th < 1) fail(BWT_HIP_EINVAL, "invalid argument: bwt_rec_threshold >= 1");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  std::unique_ptr<Slice> s(new Slice());
+  s->d = dist_build(c, t, th, ns, seg);
+  s->rank = t->rank;
+  i64 first = 0;
+  for (int j = 0; j < t->rank; j++) first += s->d->sizes[(size_t)j];
+  s->first = first;
+  *out = reinterpret_cast<bwt_hip_slice *>(s.release());
+  DIST_END
+}
+
+int bwt_hip_slice_info(const bwt_hip_slice *s_, int64_t *first, int64_t *size, int64_t *s_rank, int64_t *e_rank, int64_t *n_samples) {
+  DIST_BEGIN
+  if (!s_) fail(BWT_HIP_EINVAL, "invalid argument: slice");
+  const Slice *s = reinterpret_cast<const Slice *>(s_);
+  const bool root = s->rank == 0;
+  if (first) *first = s->first;
+  if (size) *size = s->d->sizes[(size_t)s->rank];
+  if (s_rank) *s_rank = root ? s->d->s_rank : -1;
+  if (e_rank) *e_rank = root ? s->d->e_rank : -1;
+  if (n_samples) *n_samples = root ? s->d->n_samp : 0;
+  DIST_END
+}
+
+int bwt_hip_slice_L_device(const bwt_hip_slice *s_, const uint8_t **L_dev) {
+  DIST_BEGIN
+  if (!s_ || !L_dev) fail(BWT_HIP_EINVAL, "invalid argument: slice, L_dev");
+  *L_dev = reinterpret_cast<const Slice *>(s_)->d->L.get();
+  DIST_END
+}
+
+int bwt_hip_slice_get_L(bwt_hip_ctx *ctx, const bwt_hip_slice *s_, uint8_t *L_host) {
+  DIST_BEGIN
+  if (!ctx || !s_ || !L_host) fail(BWT_HIP_EINVAL, "invalid argument: ctx, slice, L_host");
+  const Slice *s = reinterpret_cast<const Slice *>(s_);
+  const i64 size = s->d->sizes[(size_t)s->rank];
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (size > 0) HIP_CHECK(hipMemcpyAsync(L_host, s->d->L.get(), (size_t)size, hipMemcpyDeviceToHost, ctx->c.stream));
+  ctx->c.sync();
+  DIST_END
+}
+
+int bwt_hip_slice_get_samples(bwt_hip_ctx *ctx, const bwt_hip_slice *s_, int64_t *rank_out, int64_t *pos_out, int64_t cap) {
+  DIST_BEGIN
+  if (!ctx || !s_ || !rank_out || !pos_out) fail(BWT_HIP_EINVAL, "invalid argument: ctx, slice, rank_out, pos_out");
+  const Slice *s = reinterpret_cast<const Slice *>(s_);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  if (s->rank != 0) fail(BWT_HIP_EINVAL, "the samples are on rank 0");
+  const i64 k = s->d->n_samp < cap ? s->d->n_samp : cap;
+  if (k > 0) {
+    DBuf<i64> wr(c, (size_t)k), wp(c, (size_t)k);
+    launch1d(c, k_u32_to_i64, (u64)k, (const u32 *)s->d->samp_rank.get(), (u64)k, wr.get());
+    launch1d(c, k_u32_to_i64, (u64)k, (const u32 *)s->d->samp_pos.get(), (u64)k, wp.get());
+    HIP_CHECK(hipMemcpyAsync(rank_out, wr.get(), (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(pos_out, wp.get(), (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+  }
+  DIST_END
+}
+
+void bwt_hip_slice_free(bwt_hip_slice *s) { delete reinterpret_cast<Slice *>(s); }
+
+int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns,
+                        int64_t seg, uint8_t *L_host, int64_t *s_rank, int64_t *e_rank, int64_t *samp_rank,
+                        int64_t *samp_pos, int64_t samp_cap, int64_t *n_samples, int *used) {
+  DIST_BEGIN
+  if (!devices || n_devices < 1 || !T_host || !L_host || n < 1 || th < 1) fail(BWT_HIP_EINVAL, "invalid argument: devices, T_host, L_host, n >= 1, bwt_rec_threshold >= 1");
+  int world = 1, depth = 0;
+  while (world * 2 <= n_devices && tree_reaches(n, th, depth + 1)) {
+    world *= 2;
+    depth++;
+  }
+  if (used) *used = world;
+  std::vector<bwt_hip_transport *> tr((size_t)world, nullptr);
+  int rc0 = bwt_hip_transport_local(world, tr.data());
+  if (rc0 != 0) return rc0;
+  std::vector<int> rcs((size_t)world, 0);
+  std::vector<std::string> msgs((size_t)world);
+  auto body = [&](int k) {
+    bwt_hip_ctx *ctx = nullptr;
+    bwt_hip_slice *sl = nullptr;
+    int rc = bwt_hip_create(devices[k], &ctx);
+    if (rc == 0) rc = bwt_hip_set_text(ctx, T_host, n);
+    // a rank that cannot start still has to meet the others: without its transfers they would wait for ever;
+    // the in-process transport wakes them when one member reports a failure
+    if (rc == 0) rc = bwt_hip_dist_pmbwt(ctx, tr[(size_t)k], th, ns, seg, &sl);
+    if (rc != 0) {
+      LocalEnd *e = (LocalEnd *)tr[(size_t)k]->self;
+      std::lock_guard<std::mutex> lock(e->hub->mu);
+      e->hub->broken = true;
+      e->hub->cv.notify_all();
+    }
+    if (rc == 0) {
+      int64_t first = 0, size = 0, sr = -1, er = -1, nsmp = 0;
+      rc = bwt_hip_slice_info(sl, &first, &size, &sr, &er, &nsmp);
+      if (rc == 0) rc = bwt_hip_slice_get_L(ctx, sl, L_host + first);
+      if (rc == 0 && k == 0) {
+        if (s_rank) *s_rank = sr;
+        if (e_rank) *e_rank = er;
+        if (n_samples) *n_samples = nsmp;
+        if (samp_rank && samp_pos && samp_cap > 0) rc = bwt_hip_slice_get_samples(ctx, sl, samp_rank, samp_pos, samp_cap);
+      }
+    }
+    if (rc != 0) msgs[(size_t)k] = bwt_hip_last_error();
+    rcs[(size_t)k] = rc;
+    bwt_hip_slice_free(sl);
+    bwt_hip_transport_free(tr[(size_t)k]);
+    if (ctx) bwt_hip_destroy(ctx);
+  };
+  std::vector<std::thread> th_;
+  for (int k = 1; k < world; k++) th_.push_back(std::thread(body, k));
+  body(0);
+  for (auto &x : th_) x.join();
+  for (int k = 0; k < world; k++)
+    if (rcs[(size_t)k] != 0) fail(rcs[(size_t)k], "rank %d: %s", k, msgs[(size_t)k].c_str());
+  DIST_END
+}

@@ -334,9 +334,18 @@ struct ResamplePart {
 };
 void resample_part(Ctx &c, const ResamplePart &R);
 
+// api.hip: bwt_rec (leaf iff b-a <= th, else split at (a+b)/2 and merge); the calling thread's error message
+Block *build_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg);
+void set_last_error(const char *msg);
+
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
 void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);
 struct WmView;
 WmView make_view(const Block &blk);
 
 }  // namespace bwtamd
+
+// the C-ABI's context handle
+struct bwt_hip_ctx {
+  bwtamd::Ctx c;
+};

@@ -175,6 +175,20 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             d = dist_merge.pmbwt_dist(dops, rank, world, n, lpr, dist, groups, dev, False)
             ctx.sync()
             return _Held(d)
+    elif algo == "native":
+        # the same schedule in C++ (bwt_hip_dist_pmbwt) over the library's own RCCL transport: ncclSend / ncclRecv
+        # on a communicator of its own; torch.distributed only carries the communicator's id and the timing
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.from_numpy(bwt_amd.Transport.rccl_unique_id()))
+        dist.broadcast(uid, 0)
+        transport = bwt_amd.Transport.rccl(ctx, uid.cpu().numpy(), rank, world)
+        th_native = leaf_threshold(n, total_leaves)
+
+        def step():
+            s = ctx.dist_pmbwt(transport, th_native, ns, args.seg)
+            ctx.sync()
+            return s
     else:
         ops = HipOps(ctx, ns, args.seg, True, dev)
 
@@ -216,12 +230,13 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
             "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
                                     "subtree (RCCL point-to-point + all-to-all); L stays sliced over the GPUs, samples on rank 0"
-                                    if algo == "dist" else
+                                    if algo in ("dist", "native") else
                                     "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0")
                                    % (n, total_leaves, world),
                        "n": n, "sigma": args.sigma, "leaves": total_leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                        "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True,
-                       "parallelism": "leaf-sharded x%d, %s" % (world, "distributed merges" if algo == "dist" else "pairwise merge tree")},
+                       "parallelism": "leaf-sharded x%d, %s" % (world, {"dist": "distributed merges (torch.distributed)",
+                                                                        "native": "distributed merges (C++ driver, RCCL send/recv)"}.get(algo, "pairwise merge tree"))},
             # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
             "roofline": roofline(timers), "cpu_baseline": None,
             "phases_rank0": phase_table(timers, args.steps),

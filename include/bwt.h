@@ -26,6 +26,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -342,6 +343,36 @@ namespace bwt {
     clock_gettime(CLOCK_MONOTONIC, &w0);
     tsc_t t0 = get_tsc();
 
+    if (opt.n_gpus > 1) {
+      /* One host thread and one context per GPU inside bwt_hip_pmbwt_multi; the blocks live and die there, so the
+         result has no device handle (dev = 0) and the per-phase device timers are not collected. */
+      int * devs = new int[opt.n_gpus];
+      for (int k = 0; k < opt.n_gpus; k++) devs[k] = opt.device + k;
+      if (const char * list = getenv("BWT_HIP_DEVICES")) { /* e.g. "0,0,0,0": ranks that share a GPU (tests) */
+        int k = 0;
+        for (const char * p = list; *p && k < opt.n_gpus; k++) { devs[k] = atoi(p); while (*p && *p != ',') p++; if (*p) p++; }
+      }
+      bwt t;
+      t.init(T, n, L, 0, n);
+      idx_t cap = min(n, opt.ssa_n_samples);
+      idx_t * rk = new idx_t[cap];
+      idx_t * ps = new idx_t[cap];
+      int64_t s = -1, e = -1, ns = 0;
+      int used = 0;
+      bwt_hip_ok(bwt_hip_pmbwt_multi(devs, opt.n_gpus, T, n, opt.bwt_rec_threshold, opt.ssa_n_samples, opt.build_gap_segment_sz,
+                                     L, &s, &e, (int64_t *)rk, (int64_t *)ps, cap, &ns, &used));
+      t.s_rank = s;
+      t.e_rank = e;
+      t.ssa.load(cap, rk, ps, ns < cap ? ns : cap, mem);
+      delete[] rk;
+      delete[] ps;
+      delete[] devs;
+      tsc_t t1 = get_tsc();
+      stat.end(ts_event_pmbwt);
+      stat.print();
+      printf("%llu clocks to build bwt for %ld chars\n", t1 - t0, n);
+      return t;
+    }
     bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device, true);
     if (stat_level >= 1) { bwt_hip_ok(bwt_hip_set_timing(c, 1)); bwt_hip_ok(bwt_hip_reset_timers(c)); }
     bwt_hip_block * h = 0;

@@ -219,6 +219,67 @@ int bwt_hip_dist_resample(bwt_hip_ctx *ctx, const int64_t *l_rank_dev, const int
                           int64_t right_before, const uint32_t *g_dev, int64_t p_lo, int64_t p_hi,
                           int64_t *o_rank_dev, int64_t *o_pos_dev, int64_t *kept);
 
+/* ---- the whole build over several GPUs -------------------------------------------------------------- */
+/* The reference builds in one address space.  Here the recursion tree of bwt::bwt_rec (include/bwt.h:854-865) is cut
+   at depth log2(world): rank k builds the k-th subtree on its own GPU, and every merge above (include/bwt.h:791-847)
+   runs on all GPUs of its subtree through the bwt_hip_dist_* steps, with the left block, the g values, the right
+   symbols and the samples exchanged in between.  A rank is a (context, transport) pair: a process per GPU over
+   RCCL, or a thread per GPU inside one process over peer copies.  Every rank holds the whole text. */
+
+/* One send or receive of device memory (bytes) to / from rank `peer`. */
+typedef struct bwt_hip_p2p {
+  int peer;
+  int is_send;
+  void *buf;
+  int64_t bytes;
+} bwt_hip_p2p;
+
+/* How ranks move device memory between them.  exchange() performs all `n_ops` transfers of the calling rank and
+   returns when they are complete; the matching calls of the peers list the same transfers from their side, in the
+   same order per pair of ranks.  A caller may bring its own (MPI, a test harness); two ship with the library. */
+typedef struct bwt_hip_transport {
+  void *self;
+  int rank, world;
+  int (*exchange)(void *self, int n_ops, const bwt_hip_p2p *ops);
+  void (*destroy)(void *self);
+} bwt_hip_transport;
+
+/* RCCL over xGMI, one process (or thread) per GPU: ncclSend/ncclRecv grouped per exchange.  id: 128 bytes from
+   bwt_hip_rccl_unique_id on rank 0, handed to the other ranks by the launcher (file, MPI, torch.distributed store).
+   librccl.so is loaded when the first of these is called. */
+int bwt_hip_rccl_unique_id(uint8_t id[128]);
+int bwt_hip_transport_rccl(bwt_hip_ctx *ctx, const uint8_t id[128], int rank, int world, bwt_hip_transport **out);
+/* Ranks that are threads of this process: `world` transports that copy peer to peer (hipMemcpyPeerAsync over
+   xGMI between GPUs; plain device copies where ranks share a GPU).  out[k] belongs to rank k. */
+int bwt_hip_transport_local(int world, bwt_hip_transport **out);
+void bwt_hip_transport_free(bwt_hip_transport *t);
+
+/* This rank's share of a block that is spread over the ranks: slice `rank` of L (by rank range), the samples and
+   special ranks on rank 0 only. */
+typedef struct bwt_hip_slice bwt_hip_slice;
+/* bwt::pmbwt (include/bwt.h:867-883) over t->world ranks (a power of two); called by every rank with its own
+   context, all of which hold the same text.  The tree is the reference's for this bwt_rec_threshold; it must have
+   at least `world` leaves at depth log2(world) (BWT_HIP_EINVAL otherwise). */
+int bwt_hip_dist_pmbwt(bwt_hip_ctx *ctx, bwt_hip_transport *t, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
+                       int64_t build_gap_segment_sz, bwt_hip_slice **out);
+/* first: rank of the slice's first symbol; the other outputs as bwt_hip_block_info (valid on rank 0, -1 elsewhere). */
+int bwt_hip_slice_info(const bwt_hip_slice *s, int64_t *first, int64_t *size, int64_t *s_rank, int64_t *e_rank,
+                       int64_t *n_samples);
+int bwt_hip_slice_L_device(const bwt_hip_slice *s, const uint8_t **L_dev);
+int bwt_hip_slice_get_L(bwt_hip_ctx *ctx, const bwt_hip_slice *s, uint8_t *L_host);
+int bwt_hip_slice_get_samples(bwt_hip_ctx *ctx, const bwt_hip_slice *s, int64_t *rank_out, int64_t *pos_out, int64_t cap);
+void bwt_hip_slice_free(bwt_hip_slice *s);
+
+/* The same in one call for a host program that owns several GPUs: one thread and one context per entry of
+   `devices` (a device may be listed more than once: its ranks then share it), the text uploaded to each, slices
+   gathered into L_host[0:n).  Sample outputs as bwt_hip_block_get_samples; *n_samples receives their number.
+   n_devices = 1 is the plain single-GPU build.  If the tree has fewer than n_devices leaves at that depth, the
+   largest power of two of GPUs that it feeds is used; *used (may be null) says how many. */
+int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t bwt_rec_threshold,
+                        int64_t ssa_n_samples, int64_t build_gap_segment_sz, uint8_t *L_host, int64_t *s_rank,
+                        int64_t *e_rank, int64_t *samp_rank, int64_t *samp_pos, int64_t samp_cap, int64_t *n_samples,
+                        int *used);
+
 /* ---- observability ------------------------------------------------------- */
 
 /* level > 0 records a hipEvent pair around every phase on the context's stream. */

@@ -46,6 +46,9 @@ namespace bwt {
     int assert_level;
     /* MI355X additions */
     int device; /* HIP device ordinal used by this process, default 0 */
+    int n_gpus; /* pmbwt: GPUs to spread the build over, devices device .. device+n_gpus-1 (0 or 1: one GPU).  The
+                   recursion tree is the one bwt_rec_threshold gives; as many GPUs are used as it has subtrees at
+                   their depth (a power of two) */
 
     bwt_opt() {
       mem_budget = 0;
@@ -56,6 +59,7 @@ namespace bwt {
 #undef X
       assert_level = 0;
       device = 0;
+      n_gpus = 0;
     }
 
     /* number of partial BWTs alive on the right spine of the recursion */

@@ -85,3 +85,13 @@ def test_stat_table_credits_every_device_phase():
     for ev, calls in want.items():
         assert ev in rows, (ev, sorted(rows))
         assert rows[ev][1] == calls and rows[ev][0] > 0, (ev, rows[ev])
+
+
+def test_cli_over_several_ranks_that_share_the_gpu():
+    """bwt_opt::n_gpus through the CLI: four ranks (threads, one context each; BWT_HIP_DEVICES puts them on the one
+    GPU at hand), host T in, host L and samples out, round trip by the host's ibwt (the blocks died with the ranks)."""
+    env = dict(os.environ, BWT_HIP_DEVICES="0,0,0,0")
+    r = subprocess.run([need(os.path.join(OWN, "pmbwt")), "--alpha_min", "a", "--alpha_max", "d", "--algo_alpha", "1", "--n_gpus", "4",
+                        "-t", "30000", "400000"], capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "checking result ... OK" in out, out[-2000:]

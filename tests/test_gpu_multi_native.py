@@ -1,0 +1,75 @@
+"""The C++ multi-GPU driver (bwt_hip_dist_pmbwt / bwt_hip_pmbwt_multi, include/bwt_hip.h): bwt::pmbwt
+(reference include/bwt.h:867-883) with the tree cut at depth log2(ranks) and every upper merge spread over the
+ranks of its subtree.  One GPU is at hand here, so the ranks are threads of this process that share it
+(in-process transport): the schedule, the partition of every merge and the sample placement are the ones
+several GPUs run; only the copies stay on one device.  Against the oracle and the single-GPU build."""
+import numpy as np
+import pytest
+
+import bwt_amd
+from oracle import Oracle, gen_repetitive, gen_text
+from tests.gpu_util import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_oracle(T, sigma, world, th, ns, seg=0):
+    n = len(T)
+    L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, ns, seg)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (L == ob.L).all()
+    assert (s_rank, e_rank) == (ob.s_rank, ob.e_rank)
+    orr, op = ob.samples()
+    assert (r == orr).all() and (p == op).all()
+    return used
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_native_multi_against_oracle(world):
+    T = gen_text(200000, 42, 4)
+    assert _same_as_oracle(T, 4, world, 200000 // world // 2 + 1, 3000) == world  # two leaves per rank
+    assert _same_as_oracle(T, 4, world, 200000 // world + 1, 777, 100) == world   # one leaf per rank
+
+
+def test_native_multi_other_texts():
+    assert _same_as_oracle(gen_text(150000, 7, 255), 255, 4, 20000, 2000) == 4
+    assert _same_as_oracle(gen_text(99991, 9, 26), 26, 8, 7000, 500, 333) == 8
+    assert _same_as_oracle(gen_repetitive(3000, 30, 0.001, seed=43, sigma=4), 4, 4, 12000, 700) == 4
+    # skewed: nearly all right suffixes fall into few gaps, parts of very different sizes
+    T = np.concatenate([gen_text(6001, 3, 4)[:-1], np.full(5999, 2, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
+    assert _same_as_oracle(T, 4, 8, 1000, 300, 64) == 8
+
+
+def test_fewer_subtrees_than_gpus():
+    """A threshold that leaves two leaves feeds two of the four ranks."""
+    T = gen_text(100000, 11, 4)
+    assert _same_as_oracle(T, 4, 4, 50000, 1000) == 2
+    assert _same_as_oracle(T, 4, 4, 100000, 1000) == 1
+
+
+def test_native_multi_matches_single_gpu_at_2e7(ctx):
+    n = 20000000
+    ctx.gen_text(n, 42, 4)
+    T = ctx.get_text()
+    ns = 100000
+    one = ctx.pmbwt(n // 8 + 1, ns)
+    L1, (r1, p1) = one.L, one.samples()
+    L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * 8, T, n // 8 + 1, ns)
+    assert used == 8 and (L == L1).all() and (s_rank, e_rank) == (one.s_rank, one.e_rank)
+    assert (r == r1).all() and (p == p1).all()
+    one.free()
+
+
+def test_rccl_transport_with_one_rank(ctx):
+    """The RCCL transport comes up (library found, communicator created) and carries a one-rank build."""
+    T = gen_text(50000, 5, 4)
+    ctx.set_text(T)
+    t = bwt_amd.Transport.rccl(ctx, bwt_amd.Transport.rccl_unique_id(), 0, 1)
+    s = ctx.dist_pmbwt(t, 20000, 400)
+    blk = ctx.pmbwt(20000, 400)
+    assert (s.first, s.size) == (0, len(T)) and (s.L == blk.L).all() and (s.s_rank, s.e_rank) == (blk.s_rank, blk.e_rank)
+    for x, y in zip(s.samples(), blk.samples()):
+        assert (x == y).all()
+    s.free()
+    t.close()
