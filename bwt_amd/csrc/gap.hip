@@ -36,8 +36,20 @@ struct ChainParams {
   u32 *g;             // seg * n_chains
 };
 
-// T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop)
-__device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 x, u64 y) {
+// T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop).  Eight symbols per (unaligned) load
+// while both suffixes have eight left: on repetitive texts these comparisons run for thousands of symbols.
+__device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64 x, u64 y) {
+  while (x + 8 <= n && y + 8 <= n) {
+    u64 wx, wy;
+    __builtin_memcpy(&wx, T + x, 8);
+    __builtin_memcpy(&wy, T + y, 8);
+    if (wx != wy) {
+      const int at = __builtin_ctzll(wx ^ wy) & ~7;  // the first symbol is the lowest byte
+      return ((wx >> at) & 0xFFu) < ((wy >> at) & 0xFFu);
+    }
+    x += 8;
+    y += 8;
+  }
   for (;; x++, y++) {
     u32 cx = T[x], cy = T[y];
     if (cx != cy) return cx < cy;
@@ -90,7 +102,7 @@ __device__ __forceinline__ u32 chain_head(const ChainParams &P, const u32 *base_
       u32 klo = wm_lf(P.wm, base_s, c, lo);
       u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
       if (c == e_char && khi >= e_rank) {
-        if (suffix_less(T, P.lb - 1, j)) {
+        if (suffix_less(T, P.n, P.lb - 1, j)) {
           klo += (klo >= e_rank);
           khi += 1;
         }
@@ -149,7 +161,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P, u32 H) 
     for (int c = 0; c < CPT; c++) {
       if (act[c]) {
         if (sym[c] == e_char && kk[c] >= e_rank) {
-          if (suffix_less(T, P.lb - 1, j0[c] - step)) kk[c]++;
+          if (suffix_less(T, P.n, P.lb - 1, j0[c] - step)) kk[c]++;
         }
         g[c] = kk[c];
       }

@@ -284,6 +284,186 @@ __global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64
 }
 
 // ----------------------------------------------------------------------------
+// A doubling round in one pass over the active list, for lists whose groups are short (repetitive texts:
+// every suffix is tied with the same position of the other copies).  The list is in rank order and a group's
+// members are consecutive in it, so ordering (group, rank[pos + h]) is a sort INSIDE each group: a workgroup
+// takes the groups that start in its stretch of the list, reads the secondary keys (the round's one random
+// access per suffix), ranks every member among its group in LDS, and writes positions, new group names and
+// "still tied" flags.  Eight radix passes over the list per round become one.  The inverse array is updated by
+// the compaction pass that follows, never here: a group must be ordered on ranks of ONE depth, and another
+// workgroup may be reading them.  A group longer than a workgroup holds raises *fail; nothing that counts has
+// been written then and the round is done by the radix passes.
+// ----------------------------------------------------------------------------
+constexpr int RT_THREADS = 1024;
+constexpr int RT_TILE = 2048;  // list entries whose groups a workgroup owns
+constexpr int RT_CAP = 4096;   // entries it can hold: the groups that start in its stretch may run this far
+
+struct RefineTileParams {
+  const u32 *slot, *pos, *grp;  // the active list: rank index, position, group name (rank of the group's first member)
+  u32 M;
+  const u32 *isa;
+  u32 *sa;
+  u64 a, b, e, n, h_exact, h;
+  u32 *overflow, *fail;
+  u32 *nslot, *npos, *ngrp;  // per list entry, in the new order: rank index, position, new group name
+  u8 *ntied;                 // bit 0: still tied; bit 1: the group name changed (the inverse array needs it)
+};
+
+__global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) {
+  __shared__ u32 A[RT_CAP];   // group names, later the sorted positions
+  __shared__ u32 Bp[RT_CAP];  // positions
+  __shared__ u32 Cs[RT_CAP];  // secondary keys
+  __shared__ u32 Ds[RT_CAP];  // rank indices
+  __shared__ u32 Es[RT_CAP];  // sorted secondary keys
+  __shared__ u16 gs_s[RT_CAP];  // first index of the entry's group
+  __shared__ u16 ge_s[RT_CAP];  // at a group's first index: one past its last
+  __shared__ u32 tmx[RT_THREADS];
+  __shared__ u32 scan_s[17];
+  __shared__ u32 bounds[2];
+  const u32 tid = threadIdx.x;
+  const u32 base = blockIdx.x * RT_TILE;
+  const u32 cnt = P.M - base < (u32)RT_CAP ? P.M - base : (u32)RT_CAP;
+  const u32 prev_grp = base ? P.grp[base - 1] : 0u;
+  if (tid < 2) bounds[tid] = RT_CAP;
+  for (u32 i = tid; i < cnt; i += RT_THREADS) A[i] = P.grp[base + i];
+  __syncthreads();
+  auto is_head = [&](u32 i) { return (base + i == 0) || A[i] != (i ? A[i - 1] : prev_grp); };
+  for (u32 i = tid; i < cnt; i += RT_THREADS)
+    if (is_head(i)) atomicMin(&bounds[i < (u32)RT_TILE ? 0 : 1], i);
+  __syncthreads();
+  const u32 lo = bounds[0];
+  if (lo == (u32)RT_CAP) return;  // no group starts here: the stretch belongs to a group of an earlier workgroup
+  u32 hi = bounds[1];
+  if (hi == (u32)RT_CAP) {
+    if (base + cnt == P.M) {
+      hi = cnt;
+    } else {
+      if (tid == 0) *P.fail = 1;  // the last group runs past what this workgroup holds
+      return;
+    }
+  }
+  // positions, rank indices, secondary keys (k_comp_isa's rules) of the entries lo .. hi-1
+  for (u32 i = lo + tid; i < hi; i += RT_THREADS) {
+    const u32 p = P.pos[base + i];
+    Bp[i] = p;
+    Ds[i] = P.slot[base + i];
+    const u64 q = (u64)p + P.h;
+    const u64 need = P.h > P.h_exact ? q + P.h : q + 1;
+    u32 sec;
+    if (P.e < P.n && need > P.e) {
+      if (p < P.b) *P.overflow = 1;
+      sec = 0xFFFFFFFFu - (u32)(p - P.a);
+    } else {
+      sec = q < P.e ? P.isa[q - P.a] + 1 : 0u;
+    }
+    Cs[i] = sec;
+  }
+  // first index of every entry's group: running maximum of the head indices; thread t owns entries 4t .. 4t+3
+  u32 v[4], mx = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    v[j] = (i >= lo && i < hi && is_head(i)) ? i + 1 : 0u;
+    mx = mx > v[j] ? mx : v[j];
+  }
+  u32 tot;
+  tmx[tid] = block_scan_incl<OpMax>(mx, scan_s, &tot);
+  __syncthreads();
+  u32 run = tid ? tmx[tid - 1] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    run = run > v[j] ? run : v[j];
+    if (i >= lo && i < hi) gs_s[i] = (u16)(run - 1);
+  }
+  __syncthreads();
+  for (u32 i = lo + tid; i < hi; i += RT_THREADS) {
+    if (i > lo && gs_s[i] == i) ge_s[gs_s[i - 1]] = (u16)i;
+    if (i + 1 == hi) ge_s[gs_s[i]] = (u16)hi;
+  }
+  __syncthreads();
+  // rank of every entry among its group: stable (equal keys keep the list's order)
+  u32 ni[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 i = lo + tid + r * RT_THREADS;
+    ni[r] = 0;
+    if (i < hi) {
+      const u32 s = gs_s[i], t = ge_s[s], my = Cs[i];
+      u32 below = 0;
+      for (u32 j = s; j < t; j++) {
+        const u32 x = Cs[j];
+        below += (x < my) || (x == my && j < i);
+      }
+      ni[r] = s + below;
+    }
+  }
+  __syncthreads();  // the group names in A are dead (the heads live in gs_s)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 i = lo + tid + r * RT_THREADS;
+    if (i < hi) {
+      A[ni[r]] = Bp[i];
+      Es[ni[r]] = Cs[i];
+    }
+  }
+  __syncthreads();
+  // new groups: a head where the group begins or the key changes; a key of 0 (nothing left of the suffix at this
+  // depth) is never tied (GroupIn::zero_low_unique)
+  auto new_head = [&](u32 i) { return gs_s[i] == i || Es[i] != Es[i - 1] || Es[i] == 0u; };
+  mx = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    v[j] = (i >= lo && i < hi && new_head(i)) ? i + 1 : 0u;
+    mx = mx > v[j] ? mx : v[j];
+  }
+  tmx[tid] = block_scan_incl<OpMax>(mx, scan_s, &tot);
+  __syncthreads();
+  run = tid ? tmx[tid - 1] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    run = run > v[j] ? run : v[j];
+    if (i >= lo && i < hi) {
+      const bool head = v[j] != 0;
+      const bool next_head = (i + 1 == ge_s[gs_s[i]]) || new_head(i + 1);
+      const u32 s = Ds[i], p = A[i];
+      P.sa[s] = p;
+      P.nslot[base + i] = s;
+      P.npos[base + i] = p;
+      const u32 name = Ds[run - 1];  // the new group is named by the rank of its first member, as the old one was
+      P.ngrp[base + i] = name;
+      P.ntied[base + i] = (u8)((u32)!(head && next_head) | ((u32)(name != Ds[gs_s[i]]) << 1));
+    }
+  }
+}
+
+// after k_refine_tile: the inverse array takes the new names, the still-tied entries form the next list
+struct TiedIn {
+  const u8 *tied;
+  __device__ __forceinline__ u32 operator()(size_t i) const { return tied[i] & 1u; }
+};
+struct RefineCompactOut {
+  const u8 *flags;
+  const u32 *nslot, *npos, *ngrp;
+  u32 *isa;
+  u32 a;
+  u32 *slot, *pos, *grp;
+  u32 *total;
+  size_t n;
+  __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
+    if (flags[i] & 2u) isa[npos[i] - a] = ngrp[i];  // the first part of a split group keeps its name
+    if (in != ex) {
+      slot[ex] = nslot[i];
+      pos[ex] = npos[i];
+      grp[ex] = ngrp[i];
+    }
+    if (i + 1 == n) *total = in;
+  }
+};
+
+// ----------------------------------------------------------------------------
 // ties ordered by comparing the text itself, for sparse and shallow ties.  All or
 // nothing: a group of more than DF_GROUP members or a comparison longer than
 // DF_DEPTH symbols gives up and the regular rounds take over.  Comparing the
@@ -1098,6 +1278,8 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
   const int gbits = bits_for(N);
+  bool tile_rounds = true;  // doubling rounds inside the groups (k_refine_tile) while the groups are short enough
+  int tile_retry = 0;
   if (M > 0 && !sa_w) {
     // the refinement rounds rewrite positions: give the packed layout a position array of its own
     // (tied suffixes then take their BWT symbol from the text, as in the pairs layout)
@@ -1114,20 +1296,54 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     // window position).  Sparse ties get a few text rounds first; dense or deep ties go to doubling.
     const bool text_round = !isa.get() && round < 8 && (u64)M * 16 < N;
     Phase ph(c, text_round ? "leaf_text_round" : "leaf_doubling_round", (double)M * 8 * 32);
+    if (!text_round && !isa.get()) {
+      h_exact = h;
+      isa = DBuf<u32>(c, N);
+      hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N, isa.get());
+      hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_pos, wl_grp, M, (u32)a, isa.get());
+      HIP_CHECK(hipGetLastError());
+    }
+    if (!text_round && tile_rounds) {
+      // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
+      DBuf<u32> ts(c, M), tp(c, M), tg(c, M);
+      DBuf<u8> tt(c, M);
+      HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+      RefineTileParams P{wl_slot, wl_pos, wl_grp, M, isa.get(), sa_w, (u64)a, (u64)b, (u64)e, (u64)c.n, h_exact, h,
+                         d_overflow, d_fail, ts.get(), tp.get(), tg.get(), tt.get()};
+      {
+        KernelTimer kt(c, "refine:k_refine_tile", (double)M * 25);
+        hipLaunchKernelGGL(k_refine_tile, dim3(ceil_div(M, RT_TILE)), dim3(RT_THREADS), 0, c.stream, P);
+        HIP_CHECK(hipGetLastError());
+      }
+      if (read_u32(c, d_fail) == 0) {
+        DBuf<u32> ns(c, M), np(c, M), ng(c, M);
+        scan_generic<u32, SumU32>(c, M, TiedIn{tt.get()},
+                                  RefineCompactOut{tt.get(), ts.get(), tp.get(), tg.get(), isa.get(), (u32)a, ns.get(), np.get(), ng.get(),
+                                                   d_total, M});
+        M = read_u32(c, d_total);
+        nl_slot = std::move(ns);
+        nl_pos = std::move(np);
+        nl_grp = std::move(ng);
+        wl_slot = nl_slot.get();
+        wl_pos = nl_pos.get();
+        wl_grp = nl_grp.get();
+        h = 2 * h;
+        round++;
+        if (read_u32(c, d_overflow)) return false;
+        if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
+        continue;
+      }
+      tile_rounds = false;  // long groups: the later rounds only have shorter ones, but a failed try costs a pass
+      tile_retry = round + 3;
+    } else if (!text_round && round >= tile_retry) {
+      tile_rounds = true;
+    }
     DBuf<u64> ck0(c, M), ck1(c, M);
     DBuf<u32> cp0(c, M), cp1(c, M);
     if (text_round) {
       hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos,
                          wl_grp, M, (u32)h, c.sym_bits, K1, ck0.get(), cp0.get());
     } else {
-      if (!isa.get()) {
-        h_exact = h;
-        isa = DBuf<u32>(c, N);
-        hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N,
-                           isa.get());
-        hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_pos, wl_grp, M,
-                           (u32)a, isa.get());
-      }
       hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, isa.get(), (u64)a, (u64)b,
                          (u64)e, (u64)c.n, h_exact, wl_pos, wl_grp, M, h, ck0.get(), cp0.get(), d_overflow);
     }
