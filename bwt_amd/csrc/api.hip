@@ -796,7 +796,7 @@ static void test_sort(Ctx &c, K *keys, u32 *vals, i64 n, int b0, int b1) {
   if (sizeof(K) == 8)
     cur = radix_sort_u64(c, (u64 **)kk, vv, (size_t)n, b0, b1);
   else
-    cur = radix_sort_u32(c, (u32 **)kk, vv, (size_t)n, b0, b1);
+    cur = radix_sort_u32(c, (u32 **)kk, vv, (size_t)n, b0, b1, (!vals && b1 - b0 > 16 && b1 - b0 <= 18) ? 2 : 1);
   HIP_CHECK(hipMemcpyAsync(keys, kk[cur], (size_t)n * sizeof(K), hipMemcpyDeviceToHost, c.stream));
   if (vals) HIP_CHECK(hipMemcpyAsync(vals, vv[cur], (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
   c.sync();

@@ -82,20 +82,23 @@ __device__ __forceinline__ u32 block_scan_incl(u32 v, u32 *smem, u32 *block_tota
   return Op::apply(carry, incl);
 }
 
-// Which lanes of the wave hold the same 8-bit digit as this lane.  lo/hi come in
+// Which lanes of the wave hold the same BITS-bit digit as this lane.  lo/hi come in
 // as the two halves of the mask of participating lanes and go out as the mask of
 // this lane's peers (itself included).  One ballot per digit bit; per bit and
 // half the update  m &= ~(ballot ^ my_bit_replicated)  is a single three-input
 // bit operation on gfx950.
-__device__ __forceinline__ void match_digit8(u32 digit, u32 &lo, u32 &hi) {
+template <int BITS>
+__device__ __forceinline__ void match_digit(u32 digit, u32 &lo, u32 &hi) {
 #pragma unroll
-  for (int b = 0; b < 8; b++) {
+  for (int b = 0; b < BITS; b++) {
     const int32_t bm = __builtin_amdgcn_sbfe((int32_t)digit, b, 1);  // all ones if bit b is set
     const u64 bal = __ballot(bm < 0);
     lo = __builtin_amdgcn_bitop3_b32(lo, (u32)bal, (u32)bm, 0x90);  // lo & ~(bal ^ bm)
     hi = __builtin_amdgcn_bitop3_b32(hi, (u32)(bal >> 32), (u32)bm, 0x90);
   }
 }
+
+__device__ __forceinline__ void match_digit8(u32 digit, u32 &lo, u32 &hi) { match_digit<8>(digit, lo, hi); }
 
 // floor(x / d) for d > 0.  64-bit integer division is a long instruction sequence on the GPU; below 2^53 a
 // double division is off by at most one, which two multiplications put right.

@@ -144,14 +144,17 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
 
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
 // rounds, 2 gap histogram), so that a profiler lists their launches apart.
-template <class K, int USE, bool TEXT>
+// DB: digit bits (8, or 9 where two wider passes replace three)
+template <class K, int USE, bool TEXT, int DB = 8>
 __global__ void __launch_bounds__(RH_THREADS)
     k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk,
               TextKeys tk) {
-  __shared__ u32 cnt[RH_THREADS / 64][256];  // one row of LDS counters per wave
+  constexpr int DIG = 1 << DB;
+  static_assert(DIG <= RH_THREADS, "one thread per digit adds the rows up");
+  __shared__ u32 cnt[RH_THREADS / 64][DIG];  // one row of LDS counters per wave
   __shared__ u32 stage[TEXT ? TK_STAGE_WORDS : 1];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (u32 d = lane; d < 256; d += 64) cnt[w][d] = 0;
+  for (u32 d = lane; d < (u32)DIG; d += 64) cnt[w][d] = 0;
   const u32 tile = xcd_tile(blockIdx.x, nblk);
   const size_t tile0 = (size_t)tile * RS_TILE;
   if constexpr (TEXT) {
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(RH_THREADS)
       if (tile0 + tid * RH_ITEMS + r < n) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < (u32)DIG) {
       u32 tot = 0;
 #pragma unroll
       for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(RH_THREADS)
     if (valid) atomicAdd(&cnt[w][d], 1u);  // LDS counter of this wave; order is irrelevant for a count
   }
   __syncthreads();
-  if (tid < 256) {
+  if (tid < (u32)DIG) {
     u32 tot = 0;
 #pragma unroll
     for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
@@ -231,7 +234,7 @@ __device__ __forceinline__ u32 digit_of(K key, int shift, u32 mask) {
 // costs a fifth of its vector instructions (gap histogram: 1.19 -> 1.08 ms per pass).  The leaf sort's first
 // pass gains as little and has to stay reverse-stable for the refinement rounds.
 // SIDE: every key travels with one more byte (sd -> side_out), staged in side_s (RS_TILE bytes of LDS).
-template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE, bool ANY_ORDER = false, bool SIDE = false>
+template <class K, bool HAS_VALS, bool FULL, bool SPLIT, bool REVERSE, bool ANY_ORDER = false, bool SIDE = false, int DB = 8>
 __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[RS_ITEMS], unsigned char *buf,
                                                 u32 *gbase, u32 *scan_s, K *__restrict__ kout,
                                                 u32 *__restrict__ vout, u32 tile_n, int shift, u32 mask,
@@ -239,8 +242,9 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
                                                 u8 *__restrict__ side_out = nullptr) {
-  u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(buf);
-  u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * 256;
+  constexpr int DIG = 1 << DB;
+  u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
+  u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
   K *keys_s = reinterpret_cast<K *>(buf);
   u32 *vals_s = reinterpret_cast<u32 *>(buf + RS_TILE * sizeof(K));
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -249,7 +253,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   u32 dig[RS_ITEMS], rk[RS_ITEMS];
   if constexpr (ANY_ORDER) {
     u32 *all = cnt[0];  // one row of counters for the whole tile
-    if (tid < 256) all[tid] = 0;
+    if (tid < (u32)DIG) all[tid] = 0;
     lds_barrier();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -258,12 +262,12 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       if (FULL || wbase + r * 64 + lane < tile_n) rk[r] = atomicAdd(&all[dig[r]], 1u);
     }
     lds_barrier();
-    const u32 tot = tid < 256 ? all[tid] : 0u;
+    const u32 tot = tid < (u32)DIG ? all[tid] : 0u;
     u32 incl = wave_scan_incl_sum(tot);
-    if (lane == 63 && w < 4) scan_s[w] = incl;
+    if (lane == 63 && w < (u32)DIG / 64) scan_s[w] = incl;
     lds_barrier();
-    for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
-    if (tid < 256) {
+    for (u32 k = 0; k < w && k < (u32)DIG / 64; k++) incl += scan_s[k];
+    if (tid < (u32)DIG) {
       const u32 ds = incl - tot;
       dstart[tid] = REVERSE ? ds + tot - 1 : ds;
       gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
@@ -272,7 +276,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) rk[r] = REVERSE ? dstart[dig[r]] - rk[r] : dstart[dig[r]] + rk[r];
   } else {
-  for (u32 d = lane; d < 256; d += 64) myc[d] = 0;
+  for (u32 d = lane; d < (u32)DIG; d += 64) myc[d] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
@@ -285,7 +289,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       lo = (u32)v;
       hi = (u32)(v >> 32);
     }
-    match_digit8(d, lo, hi);
+    match_digit<DB>(d, lo, hi);
     const u32 before = count_below_lane(lo, hi);
     // The wave's LDS operations execute in program order: every peer reads the counter, then the
     // first peer adds the group's size; the next 64 keys see the sum.
@@ -299,7 +303,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   {
     // thread d < 256 owns digit d: wave counts -> wave offsets, digit totals -> tile-local digit starts
     u32 tot = 0;
-    if (tid < 256) {
+    if (tid < (u32)DIG) {
 #pragma unroll
       for (int k = 0; k < RS_WAVES; k++) {
         u32 v = cnt[k][tid];
@@ -309,10 +313,10 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     }
     // exclusive scan of the 256 digit totals: they sit in the first four waves
     u32 incl = wave_scan_incl_sum(tot);
-    if (lane == 63 && w < 4) scan_s[w] = incl;
+    if (lane == 63 && w < (u32)DIG / 64) scan_s[w] = incl;
     lds_barrier();
-    for (u32 k = 0; k < w && k < 4; k++) incl += scan_s[k];
-    if (tid < 256) {
+    for (u32 k = 0; k < w && k < (u32)DIG / 64; k++) incl += scan_s[k];
+    if (tid < (u32)DIG) {
       u32 ds = incl - tot;
       dstart[tid] = REVERSE ? ds + tot - 1 : ds;  // reverse: the digit's last slot in the tile
       gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
@@ -361,7 +365,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
 // words), so that a histogram pass reads only the half that holds its digit.
 // SIDE: 8-byte keys-only elements with a side byte each (the wide layout of the leaf sort, TextKeys::wide):
 // side_in[i] belongs to kin[i] and moves with it to side_out.  The text pass makes both from the text.
-template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false, bool SIDE = false>
+template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false, bool SIDE = false, int DB = 8>
 __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 : 8)
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
@@ -374,13 +378,14 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   // starts, then (after every thread has turned its ranks into tile positions)
   // the tile's keys and values in digit order.
   constexpr size_t STAGE_BYTES = RS_TILE * sizeof(K) + (HAS_VALS ? RS_TILE * 4 : 0);
-  constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * 256 * 4;
+  constexpr int DIG = 1 << DB;
+  constexpr size_t COUNT_BYTES = (RS_WAVES + 1) * DIG * 4;
   constexpr size_t TEXT_BYTES = TEXT ? (size_t)RS_TILE * 8 + TK_STAGE_WORDS * 4 : 0;  // key exchange + staged text
   constexpr size_t BUF0 = (STAGE_BYTES > COUNT_BYTES ? STAGE_BYTES : COUNT_BYTES) + (SIDE ? RS_TILE : 0);
   constexpr size_t BUF_BYTES = BUF0 > TEXT_BYTES ? BUF0 : TEXT_BYTES;
   __shared__ __align__(16) unsigned char buf[BUF_BYTES];
   u8 *side_s = buf + STAGE_BYTES;  // SIDE: behind the staged keys (where the text pass kept its stretch of text before)
-  __shared__ u32 gbase[256];
+  __shared__ u32 gbase[DIG];
   __shared__ u32 scan_s[17];
 
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -472,10 +477,10 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     }
   }
   if (full)
-    rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
+    rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
   else
-    rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
+    rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
 }
 
@@ -508,41 +513,42 @@ __global__ void __launch_bounds__(RH_THREADS)
   }
 }
 
-template <class K, int USE>
+template <class K, int USE, int DB = 8>
 static int radix_sort_impl(Ctx &c, K *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit) {
   if (n == 0 || end_bit <= begin_bit) return 0;
   if (n >= (1ull << 32)) fail(BWT_HIP_EINVAL, "radix sort: %zu elements exceed 2^32-1", n);
   u32 nblk = ceil_div(n, RS_TILE);
-  DBuf<u32> counts(c, (size_t)256 * nblk);
+  constexpr int DIG = 1 << DB;
+  DBuf<u32> counts(c, (size_t)DIG * nblk);
   const bool has_vals = vals[0] != nullptr;
   TextKeys none;
   memset(&none, 0, sizeof(none));
   int cur = 0;
-  for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+  for (int shift = begin_bit; shift < end_bit; shift += DB) {
+    int bits = end_bit - shift < DB ? end_bit - shift : DB;
     u32 mask = (1u << bits) - 1;
     {
       KernelTimer kt(c, (std::string(c.sort_tag) + (sizeof(K) == 8 ? "k_rs_hist_u64" : "k_rs_hist_u32")).c_str(),
                      (double)n * sizeof(K));
-      hipLaunchKernelGGL((k_rs_hist<K, USE, false>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, keys[cur], n, shift,
+      hipLaunchKernelGGL((k_rs_hist<K, USE, false, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, keys[cur], n, shift,
                          mask, counts.get(), nblk, none);
       HIP_CHECK(hipGetLastError());
     }
-    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)256 * nblk, nullptr);
+    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)DIG * nblk, nullptr);
     {
       const char *nm = sizeof(K) == 8 ? (has_vals ? "k_rs_scatter_u64_pairs" : "k_rs_scatter_u64_keys")
                                       : (has_vals ? "k_rs_scatter_u32_pairs" : "k_rs_scatter_u32_keys");
       KernelTimer kt(c, (std::string(c.sort_tag) + nm).c_str(), (double)n * 2 * (sizeof(K) + (has_vals ? 4 : 0)));
       if (has_vals)
-        hipLaunchKernelGGL((k_rs_scatter<K, true, USE, false, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+        hipLaunchKernelGGL((k_rs_scatter<K, true, USE, false, false, false, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                            keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, counts.get(), nblk,
                            none, 0u);
       else if (USE == 2 && shift == begin_bit)  // the gap histogram only counts inside buckets: the first pass may reorder
-        hipLaunchKernelGGL((k_rs_scatter<K, false, USE, false, false, USE == 2>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+        hipLaunchKernelGGL((k_rs_scatter<K, false, USE, false, false, USE == 2, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                            keys[cur], (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask,
                            counts.get(), nblk, none, 0u);
       else
-        hipLaunchKernelGGL((k_rs_scatter<K, false, USE, false, false>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+        hipLaunchKernelGGL((k_rs_scatter<K, false, USE, false, false, false, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                            keys[cur], (const u32 *)nullptr, keys[cur ^ 1], (u32 *)nullptr, n, shift, mask,
                            counts.get(), nblk, none, 0u);
       HIP_CHECK(hipGetLastError());
@@ -557,6 +563,9 @@ int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 }
 
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use) {
+  // 17 or 18 bits: two passes of 9-bit digits instead of three of 8 (shorter output runs per pass, but a pass less)
+  if (use == 2 && !vals[0] && end_bit - begin_bit > 16 && end_bit - begin_bit <= 18)
+    return radix_sort_impl<u32, 2, 9>(c, keys, vals, n, begin_bit, end_bit);
   if (use == 2) return radix_sort_impl<u32, 2>(c, keys, vals, n, begin_bit, end_bit);
   return radix_sort_impl<u32, 1>(c, keys, vals, n, begin_bit, end_bit);
 }
@@ -749,8 +758,9 @@ static bool bucket_bounds(Ctx &c, const u64 *e, size_t n, DBuf<u32> &start, u32 
 }
 
 // Round 0 with WIDE elements, for windows whose positions need all 32 bits (TextKeys::wide): radix passes on
-// the top bbits key bits only (16 < bbits <= 24: three passes, the first one -- from the text, on the
-// lowest of those bits -- reverse-stable as always), then the bucket bounds.  The caller finishes the
+// the top bbits key bits only (16 < bbits <= 24: two passes of 9-bit digits up to 18 bits, three of 8-bit digits
+// beyond; the first one -- from the text, on the lowest of those bits -- reverse-stable as always), then the
+// bucket bounds.  The caller finishes the
 // buckets from LDS (k_bucket_emit).  elems[b] / sides[b]: the two element and side-byte buffers; returns the
 // one that holds the result, or -1 if some bucket holds more than `cap` elements (nothing usable then).
 int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,
@@ -759,16 +769,57 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad wide layout (bbits %d, K0 %d, w %d, n %zu)", bbits, text.K0, text.w, n);
   if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
   const u32 nblk = ceil_div(n, RS_TILE);
-  DBuf<u32> counts(c, (size_t)256 * nblk);
-  DBuf<u8> digits(c, n);
   TextKeys none;
   memset(&none, 0, sizeof(none));
+  int cur = 0;
+  if (bbits <= 18) {
+    // two passes of 9-bit digits (the first one on the lower bbits - 9 of them)
+    DBuf<u32> counts(c, (size_t)512 * nblk);
+    TextKeys first = text;
+    first.next_digits = nullptr;
+    TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
+    if (count_keys.K0 * count_keys.w > 32) count_keys.K0 = 32 / count_keys.w;
+    const int shifts[2] = {64 - bbits, 55};
+    for (int p = 0; p < 2; p++) {
+      const int shift = shifts[p];
+      const u32 mask = p == 0 ? (1u << (bbits - 9)) - 1u : 511u;
+      if (p == 0) {
+        {
+          KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
+          hipLaunchKernelGGL((k_rs_hist<u64, 0, true, 9>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n,
+                             shift, mask, counts.get(), nblk, count_keys);
+          HIP_CHECK(hipGetLastError());
+        }
+        scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)512 * nblk, nullptr);
+        KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 10);
+        hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, false, true, 9>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                           (const u64 *)nullptr, (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask,
+                           counts.get(), nblk, first, 0u, (const u8 *)nullptr, sides[cur ^ 1]);
+        HIP_CHECK(hipGetLastError());
+      } else {
+        {
+          KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
+          hipLaunchKernelGGL((k_rs_hist<u64, 0, false, 9>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, elems[cur], n, shift, mask,
+                             counts.get(), nblk, none);
+          HIP_CHECK(hipGetLastError());
+        }
+        scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)512 * nblk, nullptr);
+        KernelTimer kt(c, "leaf:k_rs_scatter_u64_side", (double)n * 18);
+        hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, false, true, 9>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                           elems[cur], (const u32 *)nullptr, elems[cur ^ 1], (u32 *)nullptr, n, shift, mask, counts.get(), nblk,
+                           none, 0u, (const u8 *)sides[cur], sides[cur ^ 1]);
+        HIP_CHECK(hipGetLastError());
+      }
+      cur ^= 1;
+    }
+  } else {
+  DBuf<u32> counts(c, (size_t)256 * nblk);
+  DBuf<u8> digits(c, n);
   TextKeys first = text;
   first.next_digits = digits.get();
   first.next_shift = 48;
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
   if (count_keys.K0 * count_keys.w > 32) count_keys.K0 = 32 / count_keys.w;
-  int cur = 0;
   const int shifts[3] = {64 - bbits, 48, 56};
   for (int p = 0; p < 3; p++) {
     const int shift = shifts[p];
@@ -806,6 +857,7 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
       HIP_CHECK(hipGetLastError());
     }
     cur ^= 1;
+  }
   }
   if (!bucket_bounds(c, elems[cur], n, bs->start, &bs->max_bucket, bbits, cap)) {
     bs->start = DBuf<u32>();

@@ -305,7 +305,8 @@ int bwt_hip_sync(bwt_hip_ctx *ctx);
 /* ---- primitives exposed for unit tests ----------------------------------- */
 
 /* Stable LSD radix sort of host arrays on the device, key bits [begin_bit,end_bit);
-   vals may be null. */
+   vals may be null.  u32 keys without values on 17 or 18 bits take the gap histogram's variant (two passes of
+   9-bit digits, the first in any order): sorted on those bits, not stable. */
 int bwt_hip_test_sort_u64(bwt_hip_ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit, int end_bit);
 int bwt_hip_test_sort_u32(bwt_hip_ctx *ctx, uint32_t *keys, uint32_t *vals, int64_t n, int begin_bit, int end_bit);
 /* op 0: exclusive sum, op 1: inclusive max; in place on a host array. */

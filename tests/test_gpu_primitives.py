@@ -62,3 +62,16 @@ def test_sort_skewed_digits(ctx):
     gk, gv = ctx.test_sort(keys, vals)
     order = np.argsort(keys, kind="stable")
     assert (gk == keys[order]).all() and (gv == vals[order]).all()
+
+
+@pytest.mark.parametrize("n,lo,hi", [(7, 13, 31), (8192, 13, 30), (100001, 14, 32), (3000000, 13, 31), (3000000, 0, 17)])
+def test_sort_keys_u32_on_17_or_18_bits(ctx, n, lo, hi):
+    """The gap histogram's sort on the high bits of g (two passes of 9-bit digits, the first in any order): the result
+    is ordered on those bits and is a permutation of the input."""
+    rng = np.random.RandomState(n % 977 + lo)
+    keys = rng.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    keys[:: 5] &= np.uint32(0x0000FFFF)  # a crowded digit
+    gk, _ = ctx.test_sort(keys, None, lo, hi)
+    field = (gk.astype(np.uint64) >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
+    assert (np.diff(field.astype(np.int64)) >= 0).all()
+    assert (np.sort(gk) == np.sort(keys)).all()
