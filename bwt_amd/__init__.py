@@ -53,6 +53,7 @@ def lib():
         "bwt_hip_merge": [vp, vp, vp, i64, i64, C.POINTER(vp)],
         "bwt_hip_rec": [vp, i64, i64, i64, i64, i64, C.POINTER(vp)],
         "bwt_hip_pmbwt": [vp, i64, i64, i64, C.POINTER(vp)],
+        "bwt_hip_pmbwt_host": [vp, _u8p, i64, i64, i64, i64, _u8p, C.POINTER(vp)],
         "bwt_hip_block_upload": [vp, i64, i64, _u8p, i64, i64, _i64p, _i64p, i64, C.POINTER(vp)],
         "bwt_hip_block_export_device": [vp, vp, vp, vp, vp],
         "bwt_hip_block_import_device": [vp, i64, i64, vp, i64, i64, vp, vp, i64, C.POINTER(vp)],
@@ -298,6 +299,16 @@ class Context:
         h = C.c_void_p()
         _chk(lib().bwt_hip_dist_pmbwt(self._h, transport._h, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz, C.byref(h)))
         return Slice(self, h)
+
+    def pmbwt_host(self, T, bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz=0, L_out=None):
+        """bwt::pmbwt from a host text (uint8 array) with the upload overlapped; L_out (uint8 array of len(T)) receives L."""
+        assert T.dtype == np.uint8 and T.flags["C_CONTIGUOUS"]
+        assert L_out is None or (L_out.dtype == np.uint8 and L_out.flags["C_CONTIGUOUS"] and len(L_out) >= len(T))
+        h = C.c_void_p()
+        _chk(lib().bwt_hip_pmbwt_host(self._h, _p(T, _u8p), len(T), bwt_rec_threshold, ssa_n_samples, build_gap_segment_sz,
+                                      _p(L_out, _u8p), C.byref(h)))
+        self.n = len(T)
+        return self._blk(h)
 
     def upload_block(self, a, b, L, s_rank, e_rank, samp_rank, samp_pos):
         L = np.ascontiguousarray(L, dtype=np.uint8)

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <memory>
+#include <thread>
 
 #include "../../include/bwt_hip.h"
 #include "internal.h"
@@ -112,6 +113,12 @@ void bwt_hip_destroy(bwt_hip_ctx *ctx) {
   for (auto &p : c.pending) {
     (void)hipEventDestroy(p.e0);
     (void)hipEventDestroy(p.e1);
+  }
+  for (auto &ch : c.chunks) (void)hipEventDestroy(ch.ev);
+  for (auto e : c.chunk_events) (void)hipEventDestroy(e);
+  if (c.copy_stream) {
+    (void)hipStreamSynchronize(c.copy_stream);
+    (void)hipStreamDestroy(c.copy_stream);
   }
   for (auto e : c.event_pool) (void)hipEventDestroy(e);
   for (auto &kv : c.free_blocks) (void)hipFree(kv.second);
@@ -284,6 +291,110 @@ int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t th, int64_t ns, int64_t seg, bwt_hip
     return BWT_HIP_EINVAL;
   }
   return bwt_hip_rec(ctx, 0, ctx->c.n, th, ns, seg, out);
+}
+
+// max symbol, smallest non-zero symbol and number of zeros of a host text, on a few host threads
+static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 *n_zero) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = n < (1 << 22) ? 1 : (hw > 16 ? 16 : (hw < 1 ? 1 : (int)hw));
+  std::vector<u32> mx((size_t)nt, 0), mn((size_t)nt, 255);
+  std::vector<i64> nz((size_t)nt, 0);
+  auto body = [&](int t) {
+    const i64 lo = n * t / nt, hi = n * (t + 1) / nt;
+    u8 m1 = 0, m0 = 255;  // m0: the smallest symbol counting 0 as 255 (v - 1 wraps)
+    i64 z = 0;
+    for (i64 i = lo; i < hi; i++) {
+      const u8 v = T[i], w = (u8)(v - 1);
+      m1 = v > m1 ? v : m1;
+      m0 = w < m0 ? w : m0;
+      z += (v == 0);
+    }
+    mx[(size_t)t] = m1;
+    mn[(size_t)t] = m0;  // smallest (v - 1) over v != 0, or 255 if a 0 ... see below
+    nz[(size_t)t] = z;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.push_back(std::thread(body, t));
+  body(0);
+  for (auto &x : th) x.join();
+  u32 M = 0, W = 255;
+  i64 Z = 0;
+  for (int t = 0; t < nt; t++) {
+    M = mx[(size_t)t] > M ? mx[(size_t)t] : M;
+    W = mn[(size_t)t] < W ? mn[(size_t)t] : W;  // min over all symbols of (v - 1) mod 256: zeros map to 255 and never win
+    Z += nz[(size_t)t];
+  }
+  *max_sym = (int)M;
+  *min_sym = M ? (int)W + 1 : 0;
+  *n_zero = Z;
+}
+
+int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns, int64_t seg,
+                       uint8_t *L_host, bwt_hip_block **out) {
+  API_BEGIN
+  need(ctx && T_host && out, "ctx, T_host, out");
+  need(th >= 1, "bwt_rec_threshold >= 1");
+  check_n(n);
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  drop_text(c);
+  if (!c.copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  c.T_owned = (u8 *)c.alloc((size_t)n + 64);
+  HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
+  c.sync();  // whatever used this memory before is done: the copy stream may write it
+  // first chunk: the leftmost leaf's window; then pieces of 256 MB
+  i64 b0 = n;
+  while (b0 > th && b0 >= 2) b0 = b0 / 2;
+  i64 first = b0 + (b0 / 256 > 4096 ? b0 / 256 : 4096) + 4096;
+  if (first > n) first = n;
+  auto drain = [&]() {
+    (void)hipStreamSynchronize(c.copy_stream);
+    for (auto &ch : c.chunks) c.chunk_events.push_back(ch.ev);
+    c.chunks.clear();
+  };
+  try {
+    constexpr i64 PIECE = (i64)256 << 20;
+    for (i64 off = 0; off < n;) {
+      const i64 len = off == 0 ? first : (n - off < PIECE ? n - off : PIECE);
+      HIP_CHECK(hipMemcpyAsync(c.T_owned + off, T_host + off, (size_t)len, hipMemcpyHostToDevice, c.copy_stream));
+      hipEvent_t ev;
+      if (!c.chunk_events.empty()) {
+        ev = c.chunk_events.back();
+        c.chunk_events.pop_back();
+      } else {
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      }
+      HIP_CHECK(hipEventRecord(ev, c.copy_stream));
+      off += len;
+      c.chunks.push_back({(u64)off, ev, false});
+    }
+    // the text's statistics (which symbols occur decides the layout of every sort key and rank block) come from
+    // the host copy while the first chunk is on its way
+    int max_sym = 0, min_sym = 0;
+    i64 n_zero = 0;
+    host_text_stats(T_host, n, &max_sym, &min_sym, &n_zero);
+    if (T_host[n - 1] != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", (int)T_host[n - 1]);
+    if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
+    c.T = c.T_owned;
+    c.n = n;
+    c.max_sym = max_sym;
+    c.min_sym = min_sym;
+    int bits = 1;
+    while ((max_sym >> bits) != 0) bits++;
+    c.sym_bits = bits;
+    std::unique_ptr<Block> blk(do_rec(c, 0, n, th, ns, seg));
+    c.wait_text((u64)n);
+    if (L_host) HIP_CHECK(hipMemcpyAsync(L_host, blk->L.get(), (size_t)n, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    drain();
+    *out = publish(c, blk.release());
+  } catch (...) {
+    drain();
+    (void)hipStreamSynchronize(c.stream);
+    drop_text(c);
+    throw;
+  }
+  API_END
 }
 
 int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *L_host, int64_t s_rank,

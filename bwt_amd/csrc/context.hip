@@ -118,6 +118,16 @@ void Ctx::trim() {
 
 void Ctx::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
+void Ctx::wait_text(u64 upto) {
+  for (auto &ch : chunks) {
+    if (!ch.waited) {
+      HIP_CHECK(hipStreamWaitEvent(stream, ch.ev, 0));
+      ch.waited = true;
+    }
+    if (ch.end >= upto) break;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // phase timers
 // ---------------------------------------------------------------------------

@@ -290,6 +290,7 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
     fail(BWT_HIP_EINVAL, "chains: positions [%ld,%ld) are not to the right of block [%ld,%ld)", (long)ra, (long)rb,
          (long)l.a, (long)l.b);
   build_wavelet(c, l);
+  c.wait_text((u64)c.n);  // the chains' suffix comparisons may read to the end of the text
   const u64 m = (u64)l.len(), rn = (u64)(rb - ra);
   if (m + rn >= (1ull << 32) - 2) fail(BWT_HIP_EINVAL, "merged block of %lu symbols exceeds 2^32-3", (unsigned long)(m + rn));
   ChainLayout lay;

@@ -68,6 +68,19 @@ struct Ctx {
   int min_sym = 0;  // smallest symbol in T besides the terminator (0 if there is none)
   int sym_bits = 0; // bits per symbol = floor(log2(max_sym)) + 1
 
+  // A text that is still arriving (bwt_hip_pmbwt_host): its upload runs on `copy_stream` in chunks, each with
+  // an event; wait_text(upto) makes `stream` wait for the chunks that cover T[0:upto) before work that reads
+  // them is queued.  Empty when the text is resident: wait_text then does nothing.
+  hipStream_t copy_stream = nullptr;
+  struct TextChunk {
+    u64 end;
+    hipEvent_t ev;
+    bool waited;
+  };
+  std::vector<TextChunk> chunks;
+  std::vector<hipEvent_t> chunk_events;  // spare events of finished uploads (made without timing: not for the timers' pool)
+  void wait_text(u64 upto);
+
   // caching allocator (sizes rounded up; freed blocks are kept for reuse)
   std::multimap<size_t, void *> free_blocks;
   std::unordered_map<void *, size_t> live_blocks;

@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(INV_THREADS) k_inverse(InverseParams P) {
 void inverse_block(Ctx &c, Block &blk, u8 *out_dev, i64 *mismatches) {
   if (blk.n_samp < 1) fail(BWT_HIP_EINVAL, "inverse: the block has no samples");
   build_wavelet(c, blk);
+  c.wait_text((u64)c.n);
   DBuf<unsigned long long> bad(c, 1);
   HIP_CHECK(hipMemsetAsync(bad.get(), 0, sizeof(unsigned long long), c.stream));
   InverseParams P;

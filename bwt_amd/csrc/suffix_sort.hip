@@ -1522,6 +1522,8 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
     if (slack > c.n - b) slack = c.n - b;
   }
   for (;;) {
+    // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it
+    c.wait_text((u64)(b + slack) + DF_DEPTH + 128);
     if (sort_window(c, a, b, b + slack, E, sa_out)) return;
     if (b + slack >= c.n) fail(BWT_HIP_EINTERNAL, "suffix sort overflowed a window that ends at n");
     slack = slack * 8;

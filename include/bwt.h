@@ -373,13 +373,15 @@ namespace bwt {
       printf("%llu clocks to build bwt for %ld chars\n", t1 - t0, n);
       return t;
     }
-    bwt_hip_ctx * c = device_session::get().with_text(T, n, opt.device, true);
+    /* T goes up in chunks while the first leaf is already being sorted; L comes back with the same call */
+    bwt_hip_ctx * c = device_session::get().context(opt.device);
     if (stat_level >= 1) { bwt_hip_ok(bwt_hip_set_timing(c, 1)); bwt_hip_ok(bwt_hip_reset_timers(c)); }
     bwt_hip_block * h = 0;
-    bwt_hip_ok(bwt_hip_pmbwt(c, opt.bwt_rec_threshold, opt.ssa_n_samples, opt.build_gap_segment_sz, &h));
+    bwt_hip_ok(bwt_hip_pmbwt_host(c, T, n, opt.bwt_rec_threshold, opt.ssa_n_samples, opt.build_gap_segment_sz, L, &h));
+    device_session::get().note_text(T, n);
     bwt t;
     t.init(T, n, L, 0, n);
-    fetch_block(t, c, h, mem, opt);
+    fetch_block(t, c, h, mem, opt, false);
     int64_t live, peak, reserved;
     bwt_hip_ok(bwt_hip_mem_stats(c, &live, &peak, &reserved));
     mem.note_device((size_t)peak);

@@ -94,6 +94,15 @@ int bwt_hip_rec(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t bwt_rec_threshol
 int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
                   int64_t build_gap_segment_sz, bwt_hip_block **out);
 
+/* bwt::pmbwt as the reference's caller sees it (include/bwt.h:867-883): T in host memory, L delivered to host
+   memory (L_host may be null: the block stays on the device only).  Equivalent to bwt_hip_set_text +
+   bwt_hip_pmbwt + bwt_hip_block_get_L, with the upload overlapped: the text goes up in chunks on a stream
+   of its own, the first leaf's sort starts when its window has arrived, and the text's statistics are taken from
+   the host copy meanwhile.  Page-locked buffers (bwt_hip_host_alloc) make both copies run at the link's rate.
+   The context holds the text afterwards, as after bwt_hip_set_text. */
+int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64_t bwt_rec_threshold,
+                       int64_t ssa_n_samples, int64_t build_gap_segment_sz, uint8_t *L_host, bwt_hip_block **out);
+
 /* Uploads a block computed elsewhere (host L[a:b) as the reference stores it in
    L + a, samples ordered by pos).  Lets bwt::bwt_merge run on blocks whose
    device copy was dropped.  Counterpart of passing `bwt& l` by reference

@@ -60,6 +60,9 @@ namespace bwt {
       return h ^ (uint64_t)n;
     }
 
+    /* the context has just been given T[0:n) by a call that uploads on its own (bwt_hip_pmbwt_host) */
+    void note_text(const alpha_t * T_, idx_t n_) { T = T_; n = n_; sig = signature(T_, n_); }
+
     /* makes the context hold T[0:n); `force` uploads even if it looks unchanged */
     bwt_hip_ctx * with_text(const alpha_t * T_, idx_t n_, int dev, bool force = false) {
       bwt_hip_ctx * c = context(dev);

@@ -107,3 +107,32 @@ def test_golden_1e6_from_device_generator(ctx):
     ctx.gen_text(1000000, 42, 4)
     blk = ctx.pmbwt(rec["bwt_rec_threshold"], rec["ssa_n_samples"])
     assert h8(blk.L) == rec["L_fnv"] and blk.s_rank == rec["s_rank"]
+
+
+@pytest.mark.parametrize("n,sigma,th,ns", [(12, 4, 3, 4), (5000, 3, 700, 50), (2000000, 4, 600000, 20000), (70000000, 4, 20000000, 100000),
+                                           (3000000, 255, 3000000, 5000)])
+def test_pmbwt_host_overlapped_upload(ctx, n, sigma, th, ns):
+    """bwt_hip_pmbwt_host (text uploaded in chunks while the first leaf is sorted, L downloaded by the same call) gives
+    what set_text + pmbwt + get_L give, and leaves the text in the context."""
+    T = make_text({"kind": "splitmix", "n": n, "seed": 77, "sigma": sigma})
+    Lh = np.zeros(n, dtype=np.uint8)
+    blk = ctx.pmbwt_host(T, th, ns, 0, Lh)
+    assert (blk.L == Lh).all() and blk.ibwt_mismatches() == 0
+    ctx.set_text(T)
+    ref = ctx.pmbwt(th, ns)
+    assert (ref.L == Lh).all() and (ref.s_rank, ref.e_rank) == (blk.s_rank, blk.e_rank)
+    for x, y in zip(blk.samples(), ref.samples()):
+        assert (x == y).all()
+    if n <= 5000:
+        o = Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=th, ssa_n_samples=ns)
+        assert (Oracle.pmbwt(T, o).L == Lh).all()
+
+
+def test_pmbwt_host_rejects_bad_texts(ctx):
+    import bwt_amd
+    for bad in (b"abc", b"a\0b\0", b"\0\0"):
+        with pytest.raises(bwt_amd.BwtHipError):
+            ctx.pmbwt_host(np.frombuffer(bad, dtype=np.uint8).copy(), 10, 2)
+    # the context is usable afterwards
+    ctx.set_text(np.frombuffer(b"banana\0", dtype=np.uint8))
+    assert bytes(ctx.pmbwt(10, 2).L) == b"annb\0aa"
