@@ -94,7 +94,8 @@ struct Ctx {
   u64 bucket_min_n = 100000000;  // measured crossover on random DNA: 7e7 suffixes 2.3 vs 1.9 ms, 1.4e8 suffixes 3.1 vs 3.6 ms
   // tests and tuning: take the wide bucket route wherever the alphabet allows it (not only where the packed
   // elements run out of position bits); bucket bits of that route (0 = by window length)
-  bool force_wide = false;
+  // force_wide = 1 prefers the wide route, 2 the lean route (below), both wherever the alphabet allows them
+  int force_wide = 0;
   int wide_bbits = 0;
   std::vector<PhaseTimer> timers;
   struct Pending {
@@ -244,6 +245,14 @@ struct TextKeys {
   //   element | key bits 63..32 | absolute text position, 32 bits |   side byte | key bits 31..28 | T[a+i-1], 4 bits |
   // made by the text pass when set; the side bytes travel with their elements through the later passes.
   int wide;
+  // LEAN elements (lean != 0), for windows below 2^31 suffixes of small symbols: 8 bytes and nothing on the side,
+  // because a radix pass need not keep the digit it sorts on -- after the pass that digit is known from where an
+  // element lies.  With the key's top bits cut into | d2, b2 bits | d1, b1 bits | deep, lean_deep bits |:
+  //   element  | d2 | deep | zero padding | T[a+i-1], vbits | i, pbits |
+  // The text pass sorts on d1 (bits 64-b2-b1 .. 64-b2 of the key) without storing it, the second pass on d2 over
+  // tiles that never cross the regions the first pass made (equal d1), so that the bucket of (d2, d1) starts
+  // where the second pass's scanned tile counts say.  K0 covers b2 + b1 + lean_deep bits.
+  int lean, b1, b2, lean_deep, vbits;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
@@ -266,6 +275,9 @@ void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs);
 void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket, int bbits = 16);
 int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,
                         BucketState *bs);
+// Round 0 with lean elements: two passes, then bs->start holds the bounds of the 2^(b1+b2) buckets (bucket
+// index = d2 << b1 | d1).  Returns the buffer with the result, or -1 if a bucket holds more than cap elements.
+int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 
 // ---------------------------------------------------------------------------

@@ -148,7 +148,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
 template <class K, int USE, bool TEXT, int DB = 8>
 __global__ void __launch_bounds__(RH_THREADS)
     k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk,
-              TextKeys tk) {
+              TextKeys tk, const uint2 *__restrict__ tmap = nullptr) {
   constexpr int DIG = 1 << DB;
   static_assert(DIG <= RH_THREADS, "one thread per digit adds the rows up");
   __shared__ u32 cnt[RH_THREADS / 64][DIG];  // one row of LDS counters per wave
@@ -178,6 +178,28 @@ __global__ void __launch_bounds__(RH_THREADS)
     return;
   }
   K key[RH_ITEMS];
+  if (tmap) {  // tiles of any start and length (TextKeys::lean): tmap[tile] = (first element, elements)
+    const uint2 tm = tmap[tile];
+    const K *src = keys + tm.x;
+#pragma unroll
+    for (int r = 0; r < RH_ITEMS; r++) {
+      const u32 i = (u32)r * RH_THREADS + tid;
+      key[r] = i < tm.y ? src[i] : (K)0;
+    }
+#pragma unroll
+    for (int r = 0; r < RH_ITEMS; r++) {
+      const u32 d = (u32)(key[r] >> shift) & mask;
+      if ((u32)r * RH_THREADS + tid < tm.y) atomicAdd(&cnt[w][d], 1u);
+    }
+    __syncthreads();
+    if (tid < (u32)DIG) {
+      u32 tot = 0;
+#pragma unroll
+      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
+      counts[(size_t)tid * nblk + tile] = tot;
+    }
+    return;
+  }
   const bool full = tile0 + RS_TILE <= n;
   if (full) {  // all loads issued before the first use: 16 bytes per lane and load
     constexpr int PER = 16 / sizeof(K);
@@ -241,7 +263,8 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 const u32 *__restrict__ offs, u32 nblk, u32 tile, u32 stride,
                                                 u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
-                                                u8 *__restrict__ side_out = nullptr) {
+                                                u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
+                                                u32 lean_tile0 = 0) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -350,6 +373,11 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
         klo[dst] = (u32)k;
         klo[(size_t)stride + dst] = (u32)((u64)k >> 32);  // beyond 2^32 words for windows above 2^31
       } else {
+        if constexpr (REVERSE && sizeof(K) == 8 && !HAS_VALS && !SIDE) {
+          // lean elements (TextKeys::lean) were staged with this pass's digit above the low 13 bits of their
+          // position field; the element proper has its window index there
+          if (lean_posmask) k = (K)(((u64)k & ~(u64)lean_posmask) | (u64)(lean_tile0 + ((u32)k & (u32)(RS_TILE - 1))));
+        }
         kout[dst] = k;
         if constexpr (REVERSE && sizeof(K) == 8) {  // the text pass: the next pass's digits on the side
           if (next_digits) next_digits[dst] = (u8)((u64)k >> next_shift);
@@ -370,7 +398,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
                  u32 nblk, TextKeys tk, u32 stride, const u8 *__restrict__ side_in = nullptr,
-                 u8 *__restrict__ side_out = nullptr) {
+                 u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr) {
   static_assert(!SIDE || (sizeof(K) == 8 && !HAS_VALS && !SPLIT), "side bytes go with 8-byte keys-only elements");
   u8 sd[RS_ITEMS];
   static_assert(!SPLIT || sizeof(K) == 8, "only 64-bit keys are split");
@@ -390,8 +418,16 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
 
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 tile = xcd_tile(blockIdx.x, nblk);
-  const size_t tile0 = (size_t)tile * RS_TILE;
-  const u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
+  size_t tile0 = (size_t)tile * RS_TILE;
+  u32 tile_n = (u32)((n - tile0) < (size_t)RS_TILE ? (n - tile0) : (size_t)RS_TILE);
+  if constexpr (!TEXT && !SPLIT && !HAS_VALS && !SIDE) {
+    if (tmap) {  // tiles of any start and length (TextKeys::lean)
+      const uint2 tm = tmap[tile];
+      tile0 = tm.x;
+      tile_n = tm.y;
+      if (tile_n == 0) return;
+    }
+  }
   const bool full = tile_n == RS_TILE;
 
   K key[RS_ITEMS];
@@ -427,6 +463,12 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
       } else if constexpr (SIDE) {  // wide element: key bits 63..32 | absolute position; side: key bits 31..28 | preceding symbol
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (u32)(pos0 + idx));
         sd[r] = (u8)((((u32)k >> 28) << 4) | ((u32)k & 0xFu));
+      } else if (tk.lean) {
+        // lean element as it is staged: | d2 | deep | preceding symbol | d1 above bit 13 | index in the tile |
+        const u64 top = ~0ull << (64 - tk.b2);
+        const u64 hi = ((k & top) | ((k << tk.b1) & ~top)) & (~0ull << (64 - tk.b2 - tk.lean_deep));
+        const u32 d1 = (u32)(k >> (64 - tk.b2 - tk.b1)) & ((1u << tk.b1) - 1u);
+        key[r] = (K)(hi | ((u64)((u32)k & 0xFFu) << tk.pbits) | (u64)(d1 << 13) | idx);
       } else {  // packed element: codes | preceding symbol | window index
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
       }
@@ -476,12 +518,15 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
       }
     }
   }
+  const u32 lean_posmask = (TEXT && tk.lean) ? (u32)((1ull << tk.pbits) - 1ull) : 0u;
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
-                                              tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
+                                              tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
+                                              lean_posmask, (u32)tile0);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
-                                               nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out);
+                                               nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
+                                               lean_posmask, (u32)tile0);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -867,6 +912,144 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
   bs->bbits = bbits;
   bs->pending = true;
   return cur;
+}
+
+// ----------------------------------------------------------------------------
+// Lean elements (TextKeys::lean): the second pass runs over tiles that never cross the regions of equal first
+// digit, so the first digit need not be stored and the bucket bounds fall out of the second pass's scanned
+// tile counts.
+// ----------------------------------------------------------------------------
+// One workgroup.  offs1: the first pass's scanned counts, [digit][tile]: region d begins at offs1[d * nblk].
+// Cuts every region into tiles of RS_TILE elements (the last one shorter): tfirst[d] = number of tiles in the
+// regions below d (nd1 + 1 entries), tmap[t] = (first element, elements) of tile t; the tiles from tfirst[nd1] on
+// are empty (the caller's nblk2 is an upper bound that leaves at least one of them).
+__global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ offs1, u32 nblk, u32 nd1, u32 n,
+                                                     u32 *__restrict__ tfirst, uint2 *__restrict__ tmap, u32 nblk2) {
+  __shared__ u32 rs[513], tf[513];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x;
+  if (tid < nd1) rs[tid] = offs1[(size_t)tid * nblk];
+  if (tid == nd1) rs[tid] = n;
+  __syncthreads();
+  const u32 nt = tid < nd1 ? (rs[tid + 1] - rs[tid] + RS_TILE - 1) / RS_TILE : 0u;
+  u32 total;
+  const u32 incl = block_scan_incl<OpSum>(nt, scan_s, &total);
+  if (tid < nd1) tf[tid] = incl - nt;
+  if (tid == nd1) tf[tid] = total;
+  __syncthreads();
+  if (tid <= nd1) tfirst[tid] = tf[tid];
+  for (u32 t = tid; t < nblk2; t += 1024) {
+    if (t >= total) {
+      tmap[t] = make_uint2(n, 0u);
+      continue;
+    }
+    u32 lo = 0, hi = nd1;  // the last region d with tf[d] <= t (empty regions share their tf with the next one)
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) / 2;
+      if (tf[mid] <= t) lo = mid;
+      else hi = mid;
+    }
+    const u32 t0 = rs[lo] + (t - tf[lo]) * RS_TILE;
+    const u32 left = rs[lo + 1] - t0;
+    tmap[t] = make_uint2(t0, left < (u32)RS_TILE ? left : (u32)RS_TILE);
+  }
+}
+
+// start[d2 << b1 | d1] = first element of that bucket after the second pass: the scanned count of digit d2 at the
+// first tile of region d1 (the pass is stable and its tiles follow the regions in order); start[n_buckets] = n
+__global__ void k_lean_bucket_starts(const u32 *__restrict__ offs2, u32 nblk2, const u32 *__restrict__ tfirst, int b1,
+                                     u32 n_buckets, u32 n, u32 *__restrict__ start) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_buckets) return;
+  start[k] = k == n_buckets ? n : offs2[(size_t)(k >> b1) * nblk2 + tfirst[k & ((1u << b1) - 1u)]];
+}
+
+template <int DB>
+static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, const TextKeys &count_keys, u32 *counts) {
+  const int shift = 64 - tk.b2 - tk.b1;
+  const u32 mask = (1u << tk.b1) - 1u;
+  {
+    KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
+    hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
+                       mask, counts, nblk, count_keys, (const uint2 *)nullptr);
+    HIP_CHECK(hipGetLastError());
+  }
+  scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk, nullptr);
+  KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
+  // the staged elements carry the digit above the low 13 bits of their position field
+  hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, false, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                     (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
+                     (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int DB>
+static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk2, const TextKeys &tk, u32 *counts,
+                             const uint2 *tmap) {
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  const int shift = 64 - tk.b2;
+  const u32 mask = (1u << tk.b2) - 1u;
+  {
+    KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
+    hipLaunchKernelGGL((k_rs_hist<u64, 0, false, DB>), dim3(nblk2), dim3(RH_THREADS), 0, c.stream, in, n, shift, mask, counts,
+                       nblk2, none, tmap);
+    HIP_CHECK(hipGetLastError());
+  }
+  scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk2, nullptr);
+  KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
+  hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, false, false, DB>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream, in,
+                     (const u32 *)nullptr, out, (u32 *)nullptr, n, shift, mask, counts, nblk2, none, 0u, (const u8 *)nullptr,
+                     (u8 *)nullptr, tmap);
+  HIP_CHECK(hipGetLastError());
+}
+
+int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs) {
+  const int bbits = text.b1 + text.b2;
+  if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 9 || text.pbits < 13 + text.b1 || text.pbits > 31 ||
+      n >= (1ull << 31) || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
+      64 - text.b2 - text.lean_deep < text.pbits + text.vbits || text.K0 * text.w < bbits + text.lean_deep || text.K0 * text.w > 56)
+    fail(BWT_HIP_EINTERNAL, "leaf sort: bad lean layout (b1 %d, b2 %d, deep %d, pbits %d, vbits %d, K0 %d, w %d, n %zu)", text.b1,
+         text.b2, text.lean_deep, text.pbits, text.vbits, text.K0, text.w, n);
+  if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
+  const u32 nblk = ceil_div(n, RS_TILE);
+  const u32 nd1 = 1u << text.b1, n_buckets = 1u << bbits;
+  const u32 nblk2 = nblk + nd1 + 1;
+  TextKeys first = text;
+  first.next_digits = nullptr;
+  TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
+  if (count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
+  DBuf<u32> counts(c, (size_t)512 * nblk2);
+  DBuf<u32> tfirst(c, nd1 + 1);
+  DBuf<uint2> tmap(c, nblk2);
+  if (text.b1 > 8) lean_text_pass<9>(c, elems[1], n, nblk, first, count_keys, counts.get());
+  else lean_text_pass<8>(c, elems[1], n, nblk, first, count_keys, counts.get());
+  hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)n, tfirst.get(),
+                     tmap.get(), nblk2);
+  HIP_CHECK(hipGetLastError());
+  if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get());
+  else lean_second_pass<8>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get());
+  bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
+  u32 *d_max = c.d_scalars + 12;
+  {
+    KernelTimer kt(c, "leaf:k_bucket_bounds", (double)n_buckets * 12);
+    HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_lean_bucket_starts, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk2,
+                       (const u32 *)tfirst.get(), text.b1, n_buckets, (u32)n, bs->start.get());
+    hipLaunchKernelGGL(k_bucket_max, dim3(n_buckets / 256), dim3(256), 0, c.stream, bs->start.get(), d_max, n_buckets);
+    HIP_CHECK(hipGetLastError());
+  }
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  bs->max_bucket = c.h_scalars[0];
+  if (bs->max_bucket > cap) {
+    bs->start = DBuf<u32>();
+    return -1;
+  }
+  bs->begin_bit = 0;
+  bs->bbits = bbits;
+  bs->pending = true;
+  return 0;
 }
 
 // sorts every bucket of e on bits begin_bit..47, in place

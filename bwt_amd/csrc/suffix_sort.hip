@@ -140,6 +140,21 @@ struct WideView {
   __device__ __forceinline__ u32 elem_prev(u64, u32 sd) const { return sd & 15u; }
 };
 
+// Lean elements (TextKeys::lean) after their two passes; only the bucket kernel reads them.
+//   | d2, b2 bits | deep | zero padding | preceding symbol, vbits | position - a, pbits |
+// The bucket kernel orders a bucket on the top 16 bits of `deep`; the xbits bits below those settle most of what
+// that leaves tied without a look at the text.
+struct LeanView {
+  const u64 *e;
+  u32 a, posmask, vmask;
+  int pbits, b2, xbits;
+  static constexpr bool WIDE = false;
+  __device__ __forceinline__ u32 bucket_key(u64 x, u32) const { return (u32)((x << b2) >> 48); }
+  __device__ __forceinline__ u32 elem_pos(u64 x) const { return a + ((u32)x & posmask); }
+  __device__ __forceinline__ u32 elem_prev(u64 x, u32) const { return (u32)(x >> pbits) & vmask; }
+  __device__ __forceinline__ u32 extra(u64 x) const { return xbits ? (u32)((x << (b2 + 16)) >> (64 - xbits)) : 0u; }
+};
+
 __device__ __host__ inline void set_positions(PairsView &, const u32 *) {}
 __device__ __host__ inline void set_positions(PackedView &v, const u32 *sa) { v.sa = sa; }
 
@@ -622,13 +637,16 @@ struct LeafEmit : EmitParams {
       return;
     }
     u32 smaller = 0, slack_smaller = 0, slack_ahead = 0;
+    const u32 xi = w.extra(i);  // key bits below the ones the window is ordered on (0 where there are none)
     for (u64 j = gs; j <= ge; j++) {
       if (j == i) continue;
       const u32 pj = w.pos(j);
       const bool sl = pj >= leaf_end;
       slack_ahead += (j < i && sl);
-      bool decided;
-      const bool less = text_less(T, n, (u64)pj + h, (u64)pos + h, &decided);
+      bool decided = true, less;
+      const u32 xj = w.extra(j);
+      if (xj != xi) less = xj < xi;
+      else less = text_less(T, n, (u64)pj + h, (u64)pos + h, &decided);
       if (!decided) {
         *fail = 1;
         return;
@@ -746,6 +764,7 @@ struct TileWindow {
   u64 base;
   __device__ __forceinline__ u64 key(u64 i) const { return i - base < (u64)DE_TILE ? keys[i - base] : v.key(i); }
   __device__ __forceinline__ u32 pos(u64 i) const { return i - base < (u64)DE_TILE ? poss[i - base] : v.pos(i); }
+  __device__ __forceinline__ u32 extra(u64) const { return 0u; }
 };
 
 template <class View, bool SLACK>
@@ -861,6 +880,7 @@ struct BucketWindow<PackedView> {  // the bucket from LDS, anything else (never 
   __device__ __forceinline__ u32 pos(u64 i) const {
     return i - s < (u64)cnt ? v.a + ((u32)buf[i - s] & v.posmask) : v.pos(i);
   }
+  __device__ __forceinline__ u32 extra(u64) const { return 0u; }
 };
 template <>
 struct BucketWindow<WideView> {  // key = | the bucket's 16 sorted key bits | preceding symbol, 8 bits |; outside the bucket: no match
@@ -875,6 +895,22 @@ struct BucketWindow<WideView> {  // key = | the bucket's 16 sorted key bits | pr
     return ((u64)v.bucket_key(buf[i - s], sd) << 8) | (sd & 15u);
   }
   __device__ __forceinline__ u32 pos(u64 i) const { return i - s < (u64)cnt ? (u32)buf[i - s] : 0u; }
+  __device__ __forceinline__ u32 extra(u64) const { return 0u; }
+};
+template <>
+struct BucketWindow<LeanView> {  // key = | the bucket's 16 sorted key bits | preceding symbol, 8 bits |; outside the bucket: no match
+  const LeanView &v;
+  const u64 *buf;
+  const u8 *sbuf;
+  u64 s;
+  u32 cnt;
+  __device__ __forceinline__ u64 key(u64 i) const {
+    if (i - s >= (u64)cnt) return ~0ull;
+    const u64 x = buf[i - s];
+    return ((u64)v.bucket_key(x, 0u) << 8) | v.elem_prev(x, 0u);
+  }
+  __device__ __forceinline__ u32 pos(u64 i) const { return i - s < (u64)cnt ? v.elem_pos(buf[i - s]) : 0u; }
+  __device__ __forceinline__ u32 extra(u64 i) const { return v.extra(buf[i - s]); }  // of a member of the bucket
 };
 
 // index of the k-th set bit of m (k below its population count)
@@ -1179,7 +1215,8 @@ static void launch_bucket_emit(Ctx &c, const LeafEmit<V> &em, u32 n_buckets, u32
   if (c.timing_level >= 2) {  // a counter, not a timer: which instantiation the bucket sizes selected
     const u32 variant = items <= 4 ? 4 : (items <= 6 ? 6 : (items <= 8 ? 8 : (u32)BK_ITEMS));
     char name[64];
-    snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s%s", variant, SLACK ? ",slack" : "", V::WIDE ? ",wide" : "");
+    snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s%s%s", variant, SLACK ? ",slack" : "", V::WIDE ? ",wide" : "",
+             std::is_same_v<V, LeanView> ? ",lean" : "");
     c.timers[(size_t)c.timer_index(name)].launches++;
   }
   if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
@@ -1462,6 +1499,85 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   return 1;
 }
 
+// Lean bucket route: windows of up to 2^31 suffixes of small symbols (DNA), 8-byte elements with nothing on the
+// side (TextKeys::lean).  Two radix passes -- the text pass on the lower b1 bucket bits, which it does not store,
+// the second on the top b2 -- leave 2^(b1+b2) buckets of a few thousand suffixes; k_bucket_emit orders a bucket in
+// LDS on the next 16 key bits, settles what those leave tied on the key bits below them and only then on the
+// text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing usable was written.
+static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
+  if (c.max_sym > 15 || N < c.bucket_min_n || N < 2 || N >= (1ull << 31)) return 0;
+  const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
+  const int one_based = pow2 ? 0 : 1;
+  const int w = bits_for((u64)(span + one_based));
+  // buckets of 4100 to 8200 suffixes (the largest bucket of a random text then stays below the 9216 a workgroup holds)
+  int bbits = 16;
+  while (bbits < 18 && (N >> bbits) > 8200) bbits++;
+  if (c.wide_bbits >= 2 && c.wide_bbits <= 18) bbits = c.wide_bbits;
+  if ((N >> bbits) > 8200) return 0;
+  const int b2 = bbits > 16 ? 9 : (bbits + 1) / 2, b1 = bbits - b2;
+  const int vbits = c.sym_bits;
+  int pbits = bits_for(N - 1);
+  if (pbits < 13 + b1) pbits = 13 + b1;
+  int deep = 64 - b2 - vbits - pbits;
+  if (deep > 48 - bbits) deep = 48 - bbits;
+  if (deep > 56 / w * w - bbits) deep = 56 / w * w - bbits;
+  if (deep < 16) return 0;
+  const int K0 = (bbits + deep + w - 1) / w;  // covers every stored key bit (K0 * w <= 56)
+  const int h16 = (bbits + 16) / w;           // symbols covered by the bits the buckets are ordered on
+  const int h = (bbits + deep) / w;           // whole symbols covered by all the key bits of an element
+  const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
+  if (h16 < 1 || expected_ties(sigma, h16, N) > 0.25) return 0;
+  TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0, min_sym, one_based, pbits};
+  tk.lean = 1;
+  tk.b1 = b1;
+  tk.b2 = b2;
+  tk.lean_deep = deep;
+  tk.vbits = vbits;
+  DBuf<u64> eb0(c, N), eb1(c, N);
+  u64 *el[2] = {eb0.get(), eb1.get()};
+  BucketState bs;
+  int cur;
+  {
+    Phase ph(c, "leaf_radix_sort", (double)N * (1 + 1 + 8 + 8 + 16));
+    cur = leaf_sort_text_lean(c, el, N, BK_CAP, tk, &bs);
+  }
+  if (cur < 0) return 0;
+  const u32 n_buckets = 1u << bbits;
+  u32 *d_fail = c.d_scalars + 10;
+  DBuf<u32> res;
+  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
+  Phase ph(c, "leaf_direct_emit", (double)N * 8 + (double)(b - a) * 2);
+  LeafEmit<LeanView> em;
+  memset(&em, 0, sizeof(em));
+  if (E) static_cast<EmitParams &>(em) = *E;
+  em.sa_out = sa_out ? res.get() : nullptr;
+  em.v = LeanView{el[cur], (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16};
+  em.N = N;
+  em.sym_mask = ~0xFFull;  // BucketWindow<LeanView>::key: the ordered key bits above the preceding symbol
+  em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
+  em.h = (u64)h;
+  em.leaf_end = (u32)b;
+  em.fail = d_fail;
+  em.T = c.T;
+  em.n = (u64)c.n;
+  HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+  {
+    KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
+    if (e == b) {
+      launch_bucket_emit<LeanView, false>(c, em, n_buckets, bs.max_bucket, bs.start.get(), nullptr);
+    } else {
+      DBuf<u32> sb(c, n_buckets);
+      HIP_CHECK(hipMemsetAsync(sb.get(), 0, (size_t)n_buckets * sizeof(u32), c.stream));
+      bucket_histogram(c, tk, (u64)b, (u64)(e - b), 16, sb.get(), bbits);
+      scan_generic<u32, SumU32>(c, n_buckets, ArrayIn<u32>{sb.get()}, ArrayOutExcl<u32>{sb.get(), nullptr, n_buckets});
+      launch_bucket_emit<LeanView, true>(c, em, n_buckets, bs.max_bucket, bs.start.get(), sb.get());
+    }
+  }
+  if (read_u32(c, d_fail) != 0) return 0;
+  if (sa_out) *sa_out = std::move(res);
+  return 1;
+}
+
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
 static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out) {
@@ -1475,7 +1591,9 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   const int begin_bit = low_bit & ~7;  // whole digits; the extra low bits are zero padding
   const int passes = (64 - begin_bit) / 8;
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
-  if ((!kp.pbits || c.force_wide) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
+  // windows the packed elements cannot index: lean elements up to 2^31 suffixes, wide ones beyond
+  if ((!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
+  if ((!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
     DBuf<u64> eb0(c, N), eb1(c, N);

@@ -1,0 +1,88 @@
+"""Run by test_gpu_bucket_route.py in a process of its own (the switches are read when the context is created):
+the leaf sort's lean bucket route -- 8-byte elements that do not store the first pass's digit, the second pass over
+tiles that follow the first pass's regions, ties settled on the elements' deeper key bits before the text --
+forced onto small texts, against the oracle."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bwt_amd  # noqa: E402
+from oracle import Oracle, gen_repetitive, gen_text  # noqa: E402
+from tests.bucket_route_worker import same_as_oracle  # noqa: E402
+
+
+def lean_launches(ctx):
+    return sum(v[2] for k, v in ctx.timers().items() if k.startswith("leaf:bucket_emit_items=") and k.endswith(",lean"))
+
+
+def main():
+    assert os.environ.get("BWT_HIP_BUCKET_MIN_N") == "1" and os.environ.get("BWT_HIP_FORCE_WIDE") == "2"
+    ctx = bwt_amd.Context(0)
+    ctx.set_timing(2)
+    # random DNA: one leaf, leaves with window slack, many leaves
+    T = gen_text(300000, 42, 4)
+    for th in (len(T), 150000, 40000):
+        same_as_oracle(ctx, T, 4, th, 3000)
+    assert lean_launches(ctx) >= 1 + 2 + 8, sorted(ctx.timers())
+    # the text ends in a run of the smallest symbol: equal keys that ran into the terminator
+    T = gen_text(200000, 7, 4)
+    T[-3000:-1] = 1
+    same_as_oracle(ctx, T, 4, 70000, 500)
+    # a text of few distinct 8-symbol words: most first-pass regions are empty, some tiles short
+    rng = np.random.default_rng(12)
+    words = rng.integers(1, 5, size=(5, 9), dtype=np.uint8)
+    T = np.concatenate([words[rng.integers(0, 5, 30000)].reshape(-1), np.zeros(1, dtype=np.uint8)])
+    same_as_oracle(ctx, T, 4, 100000, 800)
+    # letters with large byte values do not fit the element: the other routes take over
+    T = gen_text(120000, 3, 4)
+    T[:-1] += ord("a") - 1
+    before = lean_launches(ctx)
+    same_as_oracle(ctx, T, ord("d"), 50000, 700, 200)
+    assert lean_launches(ctx) == before
+    # alphabets that are not a power of two (one-based codes), 2 to 4 bits per symbol
+    for sigma in (2, 3, 5, 7, 8, 15):
+        T = gen_text(150000, 20 + sigma, sigma)
+        same_as_oracle(ctx, T, sigma, 60000, 800)
+    # leaf suffix arrays in the middle of the text
+    T = gen_text(250000, 11, 4)
+    ctx.set_text(T)
+    for a, b in [(0, 90000), (100000, 190000), (160000, 250000)]:
+        assert (ctx.leaf_sa(a, b) == Oracle.sa_range(T, a, b)).all(), (a, b)
+    # a skewed text and a repetitive one: the route gives up, the other layouts finish
+    T = np.concatenate([np.where(rng.random(200000) < 0.97, 1, rng.integers(1, 5, 200000)).astype(np.uint8),
+                        np.zeros(1, dtype=np.uint8)])
+    same_as_oracle(ctx, T, 4, 80000, 900)
+    T = gen_repetitive(3000, 60, 0.001, seed=43, sigma=4)
+    same_as_oracle(ctx, T, 4, 70000, 1000)
+    # 2e7 suffixes with 16, 17 and 18 bucket bits (8- and 9-bit digits) against the packed route of a plain context
+    n = 20000000
+    res = []
+    for bb in ("16", "17", "18"):
+        ctx.close()
+        os.environ["BWT_HIP_WIDE_BBITS"] = bb
+        ctx = bwt_amd.Context(0)
+        ctx.set_timing(2)
+        ctx.gen_text(n, 9, 4)
+        blk = ctx.pmbwt(n // 2 + 1, 50000)
+        assert lean_launches(ctx) == 2
+        assert blk.ibwt_mismatches() == 0
+        res.append((blk.L, blk.samples(), blk.s_rank))
+    ctx.close()
+    for k in ("BWT_HIP_WIDE_BBITS", "BWT_HIP_FORCE_WIDE", "BWT_HIP_BUCKET_MIN_N"):
+        os.environ.pop(k)
+    ctx = bwt_amd.Context(0)
+    ctx.set_timing(2)
+    ctx.gen_text(n, 9, 4)
+    blk = ctx.pmbwt(n // 2 + 1, 50000)
+    assert lean_launches(ctx) == 0
+    L, (r, p) = blk.L, blk.samples()
+    for L2, (r2, p2), s2 in res:
+        assert (L2 == L).all() and (r2 == r).all() and (p2 == p).all() and s2 == blk.s_rank
+    ctx.close()
+    print("lean route ok")
+
+
+if __name__ == "__main__":
+    main()

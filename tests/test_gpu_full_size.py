@@ -64,9 +64,9 @@ def test_golden_large_leaf(timed, rec):
     ctx.gen_text(t["n"], t["seed"], t["sigma"])
     blk = ctx.leaf(rec["a"], rec["b"], rec["ssa_n_samples"])
     check_block(blk, blk.L, rec, 0, rec["b"] - rec["a"])
-    # 5.6e8 suffixes are more than the packed 8-byte elements hold positions for (2^29): that window takes the wide
-    # route (8 + 1 byte elements, 2^17 buckets)
-    want = {"leaf_s4_whole_5.3e8": ["leaf:bucket_emit_items=9"], "leaf_s4_whole_5.6e8": ["leaf:bucket_emit_items=6,wide"],
+    # 5.6e8 suffixes are more than the packed 8-byte elements hold positions for (2^29): that window takes the lean
+    # route (8-byte elements without the first pass's digit, 2^17 buckets)
+    want = {"leaf_s4_whole_5.3e8": ["leaf:bucket_emit_items=9"], "leaf_s4_whole_5.6e8": ["leaf:bucket_emit_items=6,lean"],
             "leaf_s4_first_5e8_of_5.01e8": ["leaf:bucket_emit_items=8,slack"],
             "leaf_s4_mid_3.6e8": ["leaf:bucket_emit_items=6,slack"]}[rec["name"]]
     assert launches(ctx, "leaf:k_bucket_emit") == len(want) and variants(ctx) == want
@@ -148,8 +148,28 @@ def test_config3_n3_1e9_eight_leaves(ctx):
     ctx.trim()
 
 
-def test_n3_1e9_two_leaves_wide_route(ctx):
-    """bench.py's default on one GPU: 3.1e9 symbols as two leaves of 1.55e9 suffixes (more than 2^29: the wide
+def test_n3_1e9_two_leaves_lean_route(ctx):
+    """bench.py's default on one GPU: 3.1e9 symbols as two leaves of 1.55e9 suffixes (more than 2^29: the lean
     bucket route, 2^18 buckets) and one merge; against the same tree sorted as (key, position) pairs."""
-    _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=8,slack,wide", "leaf:bucket_emit_items=8,wide"], 8)
+    _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=8,lean", "leaf:bucket_emit_items=8,slack,lean"], 8)
+    ctx.trim()
+
+
+def test_n3_1e9_one_leaf_wide_route(ctx):
+    """3.1e9 suffixes as one leaf (more than 2^31: the wide bucket route, 8 + 1 byte elements, 2^19 buckets): the
+    same L as the two-leaf build, decoded back to the text on the device."""
+    n = 3100000000
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    ctx.gen_text(n, 42, 4)
+    one = ctx.pmbwt(n, 38750000)
+    got = variants(ctx)
+    ctx.set_timing(0)
+    assert got == ["leaf:bucket_emit_items=6,wide"], got
+    assert one.ibwt_mismatches() == 0
+    f1 = h8(one.L)
+    one.free()
+    two = ctx.pmbwt(n // 2, 38750000)
+    assert h8(two.L) == f1
+    two.free()
     ctx.trim()
