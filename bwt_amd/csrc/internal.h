@@ -97,6 +97,7 @@ struct Ctx {
   // force_wide = 1 prefers the wide route, 2 the lean route (below), both wherever the alphabet allows them
   int force_wide = 0;
   int wide_bbits = 0;
+  bool lean_any_order = true;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;

@@ -964,6 +964,8 @@ __global__ void k_lean_bucket_starts(const u32 *__restrict__ offs2, u32 nblk2, c
   start[k] = k == n_buckets ? n : offs2[(size_t)(k >> b1) * nblk2 + tfirst[k & ((1u << b1) - 1u)]];
 }
 
+// Neither pass needs a stable order: a bucket is ordered in LDS afterwards, and when that gives up nothing of this
+// sort is used.  So both rank their tiles with one LDS atomic per element (ANY_ORDER).
 template <int DB>
 static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, const TextKeys &count_keys, u32 *counts) {
   const int shift = 64 - tk.b2 - tk.b1;
@@ -977,6 +979,11 @@ static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys 
   scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk, nullptr);
   KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
   // the staged elements carry the digit above the low 13 bits of their position field
+  if (c.lean_any_order)
+    hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, true, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                       (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
+                       (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
+  else
   hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, false, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                      (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
                      (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
@@ -998,6 +1005,11 @@ static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk
   }
   scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk2, nullptr);
   KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
+  if (c.lean_any_order)
+    hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, true, false, DB>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream, in,
+                       (const u32 *)nullptr, out, (u32 *)nullptr, n, shift, mask, counts, nblk2, none, 0u, (const u8 *)nullptr,
+                       (u8 *)nullptr, tmap);
+  else
   hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, false, false, DB>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream, in,
                      (const u32 *)nullptr, out, (u32 *)nullptr, n, shift, mask, counts, nblk2, none, 0u, (const u8 *)nullptr,
                      (u8 *)nullptr, tmap);

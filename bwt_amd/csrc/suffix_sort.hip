@@ -540,7 +540,8 @@ struct EmitParams {
   u64 n, a, m;
   i64 ns;            // samples to take (already min(m, ssa_n_samples))
   u8 *L;             // may be null: suffix array only
-  u32 *samp_rank, *samp_pos, *special;
+  u64 *samp;         // slot y of the position-ordered samples: position << 32 | rank (one store per sample); ~0 = empty
+  u32 *special;
 };
 
 template <class View>
@@ -568,8 +569,7 @@ struct LeafEmit : EmitParams {
     if (rel32 == 0) special[0] = (u32)r;           // s_rank
     if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
     if (m == 1) {
-      samp_rank[0] = (u32)r;
-      samp_pos[0] = pos;
+      samp[0] = ((u64)pos << 32) | (u32)r;
       return false;
     }
     // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
@@ -579,9 +579,19 @@ struct LeafEmit : EmitParams {
     // slow and most positions are not sampled: position i is sampled iff the fractional part of
     // i*(ns-1)/(m-1) is below (ns-1)/(m-1), so one multiplication (error far below the 2^-16
     // margin for any ns < 2^36) rules out the rest.
+    // The same product also settles nearly every sampled position: with the fractional part well inside
+    // (0, ratio) the position is sampled whatever the roundings of the reference's two divisions do (they move
+    // the quotient by far less than the margin) and its slot is the product's integer part; only a fractional part
+    // within the margin of 0, of the ratio or of 1 needs the divisions themselves.
     if (rel32 == 0) return true;
-    const double f = __builtin_amdgcn_fract((double)rel32 * samp_ratio);
-    return !(f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16);
+    const double q = (double)rel32 * samp_ratio;
+    const double f = __builtin_amdgcn_fract(q);
+    if (f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16) return false;
+    if (f > 0x1p-16 && f < samp_ratio - 0x1p-16) {
+      samp[(i64)q] = ((u64)pos << 32) | (u32)r;
+      return false;
+    }
+    return true;
   }
 
   __device__ __forceinline__ void note_sample(u64 r, u32 pos) const {
@@ -590,10 +600,7 @@ struct LeafEmit : EmitParams {
     double D = (double)(i64)(m - 1);
     i64 x = (i64)floor((double)((rel - 1) * A) / D);
     i64 y = (i64)floor((double)(rel * A) / D);
-    if (x != y) {
-      samp_rank[y] = (u32)r;
-      samp_pos[y] = pos;
-    }
+    if (x != y) samp[y] = ((u64)pos << 32) | (u32)r;
   }
 
   __device__ __forceinline__ u8 sym_before(u32 pos) const { return pos ? T[pos - 1] : T[n - 1]; }
@@ -1213,15 +1220,17 @@ static void launch_bucket_emit(Ctx &c, const LeafEmit<V> &em, u32 n_buckets, u32
   if (items > MAX_ITEMS) fail(BWT_HIP_EINTERNAL, "bucket of %u elements", max_bucket);
   const dim3 grid(n_buckets), block(BK_THREADS);
   if (c.timing_level >= 2) {  // a counter, not a timer: which instantiation the bucket sizes selected
-    const u32 variant = items <= 4 ? 4 : (items <= 6 ? 6 : (items <= 8 ? 8 : (u32)BK_ITEMS));
+    const u32 variant = items <= 4 ? 4 : items;
     char name[64];
     snprintf(name, sizeof(name), "leaf:bucket_emit_items=%u%s%s%s", variant, SLACK ? ",slack" : "", V::WIDE ? ",wide" : "",
              std::is_same_v<V, LeanView> ? ",lean" : "");
     c.timers[(size_t)c.timer_index(name)].launches++;
   }
   if (items <= 4) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 4>), grid, block, 0, c.stream, em, start, slack_before);
-  else if (items <= 6) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
-  else if (items <= 8) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items == 5) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 5>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items == 6) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 6>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items == 7) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 7>), grid, block, 0, c.stream, em, start, slack_before);
+  else if (items == 8) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, 8>), grid, block, 0, c.stream, em, start, slack_before);
   else if constexpr (!V::WIDE) hipLaunchKernelGGL((k_bucket_emit<V, SLACK, BK_ITEMS>), grid, block, 0, c.stream, em, start, slack_before);
   HIP_CHECK(hipGetLastError());
 }
@@ -1505,7 +1514,7 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 // LDS on the next 16 key bits, settles what those leave tied on the key bits below them and only then on the
 // text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing usable was written.
 static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
-  if (c.max_sym > 15 || N < c.bucket_min_n || N < 2 || N >= (1ull << 31)) return 0;
+  if (N < c.bucket_min_n || N < 2 || N >= (1ull << 31)) return 0;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
   const int one_based = pow2 ? 0 : 1;
   const int w = bits_for((u64)(span + one_based));
@@ -1656,18 +1665,19 @@ DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b) {
 }
 
 struct SampFilledIn {
-  const u32 *pos;
-  __device__ __forceinline__ u32 operator()(size_t i) const { return pos[i] != 0xFFFFFFFFu; }
+  const u64 *samp;
+  __device__ __forceinline__ u32 operator()(size_t i) const { return samp[i] != ~0ull; }
 };
 struct SampCompactOut {
-  const u32 *rank_in, *pos_in;
+  const u64 *samp;
   u32 *rank_out, *pos_out;
   u32 *total;
   size_t n;
   __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
     if (in != ex) {
-      rank_out[ex] = rank_in[i];
-      pos_out[ex] = pos_in[i];
+      const u64 x = samp[i];
+      rank_out[ex] = (u32)x;
+      pos_out[ex] = (u32)(x >> 32);
     }
     if (i + 1 == n) *total = in;
   }
@@ -1684,9 +1694,8 @@ Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns_req) {
     blk->a = a;
     blk->b = b;
     blk->L = DBuf<u8>(c, (size_t)m);
-    DBuf<u32> sr(c, (size_t)ns), sp(c, (size_t)ns);
-    HIP_CHECK(hipMemsetAsync(sr.get(), 0xFF, (size_t)ns * 4, c.stream));
-    HIP_CHECK(hipMemsetAsync(sp.get(), 0xFF, (size_t)ns * 4, c.stream));
+    DBuf<u64> sv(c, (size_t)ns);
+    HIP_CHECK(hipMemsetAsync(sv.get(), 0xFF, (size_t)ns * 8, c.stream));
     u32 *special = c.d_scalars + 16;
     HIP_CHECK(hipMemsetAsync(special, 0xFF, 8, c.stream));
     EmitParams E;
@@ -1697,16 +1706,14 @@ Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns_req) {
     E.m = (u64)m;
     E.ns = ns;
     E.L = blk->L.get();
-    E.samp_rank = sr.get();
-    E.samp_pos = sp.get();
+    E.samp = sv.get();
     E.special = special;
     run_leaf_sort(c, a, b, &E, nullptr);
     blk->samp_rank = DBuf<u32>(c, (size_t)ns);
     blk->samp_pos = DBuf<u32>(c, (size_t)ns);
     u32 *d_total = c.d_scalars + 8;
-    scan_generic<u32, SumU32>(c, (size_t)ns, SampFilledIn{sp.get()},
-                              SampCompactOut{sr.get(), sp.get(), blk->samp_rank.get(), blk->samp_pos.get(),
-                                             d_total, (size_t)ns});
+    scan_generic<u32, SumU32>(c, (size_t)ns, SampFilledIn{sv.get()},
+                              SampCompactOut{sv.get(), blk->samp_rank.get(), blk->samp_pos.get(), d_total, (size_t)ns});
     HIP_CHECK(hipMemcpyAsync(c.h_scalars, special, 8, hipMemcpyDeviceToHost, c.stream));
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 2, d_total, 4, hipMemcpyDeviceToHost, c.stream));
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 3, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));

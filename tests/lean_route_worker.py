@@ -35,16 +35,18 @@ def main():
     words = rng.integers(1, 5, size=(5, 9), dtype=np.uint8)
     T = np.concatenate([words[rng.integers(0, 5, 30000)].reshape(-1), np.zeros(1, dtype=np.uint8)])
     same_as_oracle(ctx, T, 4, 100000, 800)
-    # letters with large byte values do not fit the element: the other routes take over
+    # letters with large byte values (7 bits of preceding symbol, 2-bit codes)
     T = gen_text(120000, 3, 4)
     T[:-1] += ord("a") - 1
     before = lean_launches(ctx)
     same_as_oracle(ctx, T, ord("d"), 50000, 700, 200)
-    assert lean_launches(ctx) == before
-    # alphabets that are not a power of two (one-based codes), 2 to 4 bits per symbol
-    for sigma in (2, 3, 5, 7, 8, 15):
+    assert lean_launches(ctx) == before + 4
+    # alphabets that are not a power of two (one-based codes), 2 to 8 bits per symbol
+    for sigma in (2, 3, 5, 7, 8, 15, 16, 26, 100, 255):
         T = gen_text(150000, 20 + sigma, sigma)
+        before = lean_launches(ctx)
         same_as_oracle(ctx, T, sigma, 60000, 800)
+        assert lean_launches(ctx) == before + 4, sigma
     # leaf suffix arrays in the middle of the text
     T = gen_text(250000, 11, 4)
     ctx.set_text(T)
