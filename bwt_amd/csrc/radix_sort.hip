@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
 __global__ void __launch_bounds__(RH_THREADS)
-    k_rs_hist_bytes(const u8 *__restrict__ digits, size_t n, u32 *__restrict__ counts, u32 nblk) {
+    k_rs_hist_bytes(const u8 *__restrict__ digits, size_t n, u32 *__restrict__ counts, u32 nblk,
+                    const uint2 *__restrict__ tmap = nullptr) {
   __shared__ u32 cnt[RH_THREADS / 64][256];
   static_assert(RS_TILE == RH_THREADS * 16, "one 16-byte load per thread covers the tile");
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -539,7 +540,23 @@ __global__ void __launch_bounds__(RH_THREADS)
   const u32 tile = xcd_tile(blockIdx.x, nblk);
   const size_t i0 = (size_t)tile * RS_TILE + (size_t)tid * 16;
   __builtin_amdgcn_wave_barrier();
-  if (i0 + 16 <= n) {
+  if (tmap) {
+    // a tile of any start and length (TextKeys::lean): the aligned 16-byte pieces that cover it, at most 513 of
+    // them (the array ends in 16 spare bytes), each byte counted if it lies inside the tile
+    const uint2 tm = tmap[tile];
+    const size_t first = (size_t)tm.x & ~(size_t)15, end = (size_t)tm.x + tm.y;
+    for (size_t p0 = first + (size_t)tid * 16; p0 < end; p0 += (size_t)RH_THREADS * 16) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(digits + p0);
+      const u32 wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const size_t p = p0 + (size_t)(4 * q + b);
+          if (p >= tm.x && p < end) atomicAdd(&cnt[w][(wd[q] >> (8 * b)) & 255u], 1u);
+        }
+    }
+  } else if (i0 + 16 <= n) {
     const uint4 v = *reinterpret_cast<const uint4 *>(digits + i0);
     const u32 wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -992,12 +1009,16 @@ static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys 
 
 template <int DB>
 static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk2, const TextKeys &tk, u32 *counts,
-                             const uint2 *tmap) {
+                             const uint2 *tmap, const u8 *digits) {
   TextKeys none;
   memset(&none, 0, sizeof(none));
   const int shift = 64 - tk.b2;
   const u32 mask = (1u << tk.b2) - 1u;
-  {
+  if (digits) {  // the text pass left this pass's digits as bytes on the side
+    KernelTimer kt(c, "leaf:k_rs_hist_bytes", (double)n);
+    hipLaunchKernelGGL(k_rs_hist_bytes, dim3(nblk2), dim3(RH_THREADS), 0, c.stream, digits, n, counts, nblk2, tmap);
+    HIP_CHECK(hipGetLastError());
+  } else {
     KernelTimer kt(c, "leaf:k_rs_hist_u64", (double)n * 8);
     hipLaunchKernelGGL((k_rs_hist<u64, 0, false, DB>), dim3(nblk2), dim3(RH_THREADS), 0, c.stream, in, n, shift, mask, counts,
                        nblk2, none, tmap);
@@ -1029,6 +1050,12 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   const u32 nblk2 = nblk + nd1 + 1;
   TextKeys first = text;
   first.next_digits = nullptr;
+  DBuf<u8> digits;
+  if (text.b2 <= 8) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
+    digits = DBuf<u8>(c, n + 16);
+    first.next_digits = digits.get();
+    first.next_shift = 64 - text.b2;
+  }
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
   if (count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
   DBuf<u32> counts(c, (size_t)512 * nblk2);
@@ -1039,8 +1066,8 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)n, tfirst.get(),
                      tmap.get(), nblk2);
   HIP_CHECK(hipGetLastError());
-  if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get());
-  else lean_second_pass<8>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get());
+  if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
+  else lean_second_pass<8>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), digits.get());
   bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
   u32 *d_max = c.d_scalars + 12;
   {
