@@ -10,7 +10,13 @@
 // the candidate interval [lo, hi] and LF-maps both ends: the interval shrinks
 // to a point after about log_sigma(m) steps (a backward search for the text that
 // follows).  If it has not collapsed when the chain's own positions begin, the
-// chain restarts from four times as far.
+// chain restarts from four times as far, once.  On texts with long repeats that
+// is not enough (the interval keeps every left suffix that shares the following
+// hundreds or thousands of symbols): such chains are put on a list and a second
+// launch finds their heads the reference's way (include/bwt.h:489-537 bin_search
+// over :456-481 sa), narrowed to the interval the backward search has left --
+// a binary search over its ranks, SA[rank] from the left block's samples, one
+// suffix comparison each that starts behind the symbols the interval shares.
 //
 // g values are written step-major ([step][chain]) so that a wavefront's 64
 // chains store 64 consecutive words.  The histogram uses no global atomics: g is
@@ -34,6 +40,11 @@ struct ChainParams {
   WmView wm;
   const u32 *lf_tab;  // lf_base[256], p_end[256]
   u32 *g;             // seg * n_chains
+  // chains whose head interval has not collapsed after the second try (null: keep restarting from further right)
+  u32 *defer_list, *defer_count;
+  // second launch: SA[rank] of the left block (samples as inverse.hip's RankIndex holds them)
+  const u32 *samp_bits, *by_rank, *by_rank_pos;
+  u32 ns;
 };
 
 // T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop).  Eight symbols per (unaligned) load
@@ -82,93 +93,133 @@ struct TextBack {
   }
 };
 
-// rank of the suffix at the chain's last position j0 among the left suffixes: interval phase over positions E-1 .. j0
-__device__ __forceinline__ u32 chain_head(const ChainParams &P, const u32 *base_s, TextBack &text, u64 j0) {
+// Backward search for the text behind the chain's last position j0: the interval [lo, hi] of left ranks after the
+// positions E-1 .. j0, E = j0 + 1 + ell (cut at n).  Returns E - j0, the number of symbols the left suffixes of the
+// ranks lo .. hi-1 share with T[j0:].
+__device__ __forceinline__ u64 chain_interval(const ChainParams &P, const u32 *base_s, TextBack &text, u64 j0, u64 ell,
+                                              u32 *lo_out, u32 *hi_out) {
   const u8 *__restrict__ T = P.T;
   const u32 e_char = P.e_char, e_rank = P.e_rank;
-  u32 lo, hi;
-  u64 ell = P.warm;
-  for (;;) {
-    u64 E = j0 + 1 + ell;
-    if (E > P.n) E = P.n;
-    lo = 0;
-    hi = P.m;
-    for (u64 j = E; j-- > j0;) {
-      u32 c = text(j);
-      if (c == 0) {  // the sentinel suffix is smaller than every left suffix
-        lo = hi = 0;
-        continue;
-      }
-      u32 klo = wm_lf(P.wm, base_s, c, lo);
-      u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
-      if (c == e_char && khi >= e_rank) {
-        if (suffix_less(T, P.n, P.lb - 1, j)) {
-          klo += (klo >= e_rank);
-          khi += 1;
-        }
-      }
-      lo = klo;
-      hi = khi;
+  u64 E = j0 + 1 + ell;
+  if (E > P.n) E = P.n;
+  u32 lo = 0, hi = P.m;
+  for (u64 j = E; j-- > j0;) {
+    u32 c = text(j);
+    if (c == 0) {  // the sentinel suffix is smaller than every left suffix
+      lo = hi = 0;
+      continue;
     }
-    if (lo == hi || E == P.n) break;
-    ell *= 4;
+    u32 klo = wm_lf(P.wm, base_s, c, lo);
+    u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
+    if (c == e_char && khi >= e_rank) {
+      if (suffix_less(T, P.n, P.lb - 1, j)) {
+        klo += (klo >= e_rank);
+        khi += 1;
+      }
+    }
+    lo = klo;
+    hi = khi;
   }
-  return lo;
+  *lo_out = lo;
+  *hi_out = hi;
+  return E - j0;
 }
 
-// CPT chains per thread, walked in lockstep: their rank-block reads are independent, so a wave has CPT
-// times as many random reads in flight.  Thread t owns the chains t, t + H, ... (H threads in all), which
-// keeps the stores of a wave contiguous.  Measured on a 5e8-position merge: CPT = 2 takes the same 10.4 ms
-// as CPT = 1 -- with every wave slot of the chip occupied the memory side is saturated at about 5.1e10
-// random 64-byte reads per second -- so one chain per thread is used.
-template <int CPT>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P, u32 H) {
+// rank of the suffix at the chain's last position j0 among the left suffixes.  False: the interval has not
+// collapsed after the second try and the chain is to be deferred (only when P.defer_list is set).
+__device__ __forceinline__ bool chain_head(const ChainParams &P, const u32 *base_s, TextBack &text, u64 j0, u32 *g) {
+  u32 lo, hi;
+  u64 ell = P.warm;
+  for (int attempt = 0;; attempt++) {
+    const u64 len = chain_interval(P, base_s, text, j0, ell, &lo, &hi);
+    if (lo == hi || j0 + len == P.n) break;
+    if (attempt >= 1 && P.defer_list) return false;
+    ell *= 4;
+  }
+  *g = lo;
+  return true;
+}
+
+// text position of the left suffix of rank r (include/bwt.h:456-481): LF steps to the nearest sampled rank
+__device__ __forceinline__ u64 left_sa(const ChainParams &P, const u32 *base_s, u32 r) {
+  u32 steps = 0;
+  while (steps < P.m && !((P.samp_bits[r >> 5] >> (r & 31)) & 1)) {
+    r = wm_access_lf(P.wm, base_s, r, P.e_char, P.e_rank).next;
+    steps++;
+  }
+  u32 lo = 0, hi = P.ns;  // by_rank[lo] == r
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) / 2;
+    if (P.by_rank[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  return (u64)P.by_rank_pos[lo] + steps;
+}
+
+// the chain's positions below its last one: LF steps from the head's rank g
+__device__ __forceinline__ void chain_walk(const ChainParams &P, const u32 *base_s, TextBack &text, u32 chain, u64 begin,
+                                           u64 j0, u32 g) {
+  const u8 *__restrict__ T = P.T;
+  const u32 e_char = P.e_char, e_rank = P.e_rank;
+  P.g[chain] = g;
+  for (u32 step = 1; step < P.seg; step++) {
+    const bool act = begin + step <= j0;  // false only in the tail of the short last chain
+    const u32 sym = text(act ? j0 - step : begin);
+    u32 kk = wm_lf(P.wm, base_s, sym ? sym : P.wm.min_sym, g);
+    if (act) {
+      if (sym == e_char && kk >= e_rank) {
+        if (suffix_less(T, P.n, P.lb - 1, j0 - step)) kk++;
+      }
+      g = kk;
+    }
+    // the last chain may be short: its tail gets a value above every valid g
+    __builtin_nontemporal_store(act ? g : P.m + 1, &P.g[(u64)step * P.n_chains + chain]);
+  }
+}
+
+// One chain per thread.  (Two chains per thread walked in lockstep -- twice the random reads in flight per wave --
+// take the same 10.4 ms on a 5e8-position merge: with every wave slot of the chip occupied the memory side is
+// saturated at about 5.1e10 random 64-byte reads per second.)
+__global__ void __launch_bounds__(CHAIN_THREADS) k_chains(ChainParams P) {
+  __shared__ u32 base_s[256];
+  base_s[threadIdx.x] = P.lf_tab[threadIdx.x];
+  __syncthreads();
+  const u32 chain = blockIdx.x * CHAIN_THREADS + threadIdx.x;
+  if (chain >= P.n_chains) return;
+  const u64 begin = P.ra + (u64)chain * P.seg;
+  const u64 end = (begin + P.seg < P.rb) ? begin + P.seg : P.rb;
+  const u64 j0 = end - 1;
+  TextBack text(P.T);
+  u32 g;
+  if (!chain_head(P, base_s, text, j0, &g)) {
+    P.defer_list[atomicAdd(P.defer_count, 1u)] = chain;
+    return;
+  }
+  chain_walk(P, base_s, text, chain, begin, j0, g);
+}
+
+// the deferred chains: head by binary search inside the interval a short backward search leaves
+__global__ void __launch_bounds__(CHAIN_THREADS) k_chains_deferred(ChainParams P, u32 count) {
   __shared__ u32 base_s[256];
   base_s[threadIdx.x] = P.lf_tab[threadIdx.x];
   __syncthreads();
   const u32 t = blockIdx.x * CHAIN_THREADS + threadIdx.x;
-  if (t >= H) return;
-  const u8 *__restrict__ T = P.T;
-  const u32 e_char = P.e_char, e_rank = P.e_rank;
-  u32 chain[CPT], g[CPT];
-  u64 begin[CPT], j0[CPT];
-  bool valid[CPT];
-  TextBack text[CPT];
-#pragma unroll
-  for (int c = 0; c < CPT; c++) {
-    u32 id = t + (u32)c * H;
-    valid[c] = id < P.n_chains;
-    chain[c] = valid[c] ? id : t;  // a thread without a c-th chain repeats its first one and stores nothing
-    begin[c] = P.ra + (u64)chain[c] * P.seg;
-    u64 end = (begin[c] + P.seg < P.rb) ? begin[c] + P.seg : P.rb;
-    j0[c] = end - 1;
-    text[c] = TextBack(T);
-    g[c] = chain_head(P, base_s, text[c], j0[c]);
-    if (valid[c]) P.g[chain[c]] = g[c];
+  if (t >= count) return;
+  const u32 chain = P.defer_list[t];
+  const u64 begin = P.ra + (u64)chain * P.seg;
+  const u64 end = (begin + P.seg < P.rb) ? begin + P.seg : P.rb;
+  const u64 j0 = end - 1;
+  TextBack text(P.T);
+  u32 lo, hi;
+  const u64 len = chain_interval(P, base_s, text, j0, (u64)P.warm * 4, &lo, &hi);
+  // the left suffixes of ranks lo .. hi-1 begin with T[j0 : j0+len); those below T[j0:] come first
+  while (lo < hi) {
+    const u32 mid = lo + (hi - lo) / 2;
+    const u64 p = left_sa(P, base_s, mid);
+    if (suffix_less(P.T, P.n, p + len, j0 + len)) lo = mid + 1;
+    else hi = mid;
   }
-  for (u32 step = 1; step < P.seg; step++) {
-    u32 sym[CPT];
-    bool act[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; c++) {
-      act[c] = begin[c] + step <= j0[c];  // false only in the tail of the short last chain
-      sym[c] = text[c](act[c] ? j0[c] - step : begin[c]);
-    }
-    u32 kk[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; c++) kk[c] = wm_lf(P.wm, base_s, sym[c] ? sym[c] : P.wm.min_sym, g[c]);
-#pragma unroll
-    for (int c = 0; c < CPT; c++) {
-      if (act[c]) {
-        if (sym[c] == e_char && kk[c] >= e_rank) {
-          if (suffix_less(T, P.n, P.lb - 1, j0[c] - step)) kk[c]++;
-        }
-        g[c] = kk[c];
-      }
-      // the last chain may be short: its tail gets a value above every valid g
-      if (valid[c]) __builtin_nontemporal_store(act[c] ? g[c] : P.m + 1, &P.g[(u64)step * P.n_chains + chain[c]]);
-    }
-  }
+  chain_walk(P, base_s, text, chain, begin, j0, lo);
 }
 
 // g of the right block's samples, read before the sort below destroys the layout
@@ -327,13 +378,40 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
   P.wm = make_view(l);
   P.lf_tab = l.wm.lf_base.get();
   P.g = g0.get();
+  // chains can be deferred when the left block has samples to look suffix array entries up with
+  DBuf<u32> defer_list;
+  u32 *d_count = c.d_scalars + 20;
+  P.defer_list = nullptr;
+  P.defer_count = d_count;
+  P.samp_bits = P.by_rank = P.by_rank_pos = nullptr;
+  P.ns = 0;
+  if (l.n_samp > 0 && c.defer_chains) {
+    defer_list = DBuf<u32>(c, lay.n_chains);
+    P.defer_list = defer_list.get();
+    HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
+  }
   {
     // 64-byte random reads: one rank block per level and step, one 16-byte text block every 16 steps
     Phase ph(c, "gap_chains", (double)rn * l.wm.levels + (double)rn / 16);
-    constexpr int CPT = 1;
-    const u32 H = ceil_div(lay.n_chains, CPT);
-    hipLaunchKernelGGL(k_chains<CPT>, dim3(ceil_div(H, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P, H);
+    hipLaunchKernelGGL(k_chains, dim3(ceil_div(lay.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
+  }
+  if (P.defer_list) {
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_count, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    const u32 deferred = c.h_scalars[0];
+    if (deferred > 0) {
+      RankIndex ix;
+      build_rank_index(c, l, ix);
+      P.samp_bits = ix.bits.get();
+      P.by_rank = ix.by_rank.get();
+      P.by_rank_pos = ix.by_rank_pos.get();
+      P.ns = ix.ns;
+      Phase ph(c, "gap_chains_deferred", (double)deferred * seg * l.wm.levels);
+      hipLaunchKernelGGL(k_chains_deferred, dim3(ceil_div(deferred, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P, deferred);
+      HIP_CHECK(hipGetLastError());
+      c.sync();  // the index dies with this scope
+    }
   }
   return lay;
 }

@@ -98,6 +98,9 @@ struct Ctx {
   int force_wide = 0;
   int wide_bbits = 0;
   bool lean_any_order = true;
+  // chains whose head does not come out of a short backward search are finished by a second launch that searches
+  // the left block's suffix array (gap.hip); off: they restart from further and further right instead
+  bool defer_chains = true;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;
@@ -321,6 +324,13 @@ void rank_batch(Ctx &c, Block &blk, const u8 *d_sym, const u32 *d_pos, u32 *d_ou
 // inverse.hip: the block decoded back to text (ibwt), SA[r] for a batch of ranks (sa)
 void inverse_block(Ctx &c, Block &blk, u8 *out_dev, i64 *mismatches);
 void sa_batch(Ctx &c, Block &blk, const u32 *d_rank, u32 *d_out, size_t nq);
+// inverse.hip: what SA[rank] look-ups need besides the rank structure -- a bit per rank (is it sampled?) and the
+// samples ordered by rank
+struct RankIndex {
+  DBuf<u32> bits, by_rank, by_rank_pos;
+  u32 ns = 0;
+};
+void build_rank_index(Ctx &c, Block &blk, RankIndex &ix);
 // gap.hip: the inclusive prefix sums S[i] = #{j : g_j <= i}, i in [0, m], of
 // the gap array, plus g_j at the right block's sample positions
 struct GapResult {

@@ -12,85 +12,6 @@
 
 namespace bwtamd {
 
-struct SymNext {
-  u32 sym;   // L[i]
-  u32 next;  // LF_map_mod(L[i], i), relative to the block's first rank
-};
-
-// digit at `pos` of a 4-ary level and its occurrences before pos: one 64-byte block
-__device__ __forceinline__ void wm_access_digit(const u64 *__restrict__ lvl, u32 pos, u32 *digit, u32 *before) {
-  const u32 blk = pos / WM_BLOCK_POS, off = pos - blk * WM_BLOCK_POS;
-  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM_BLOCK_WORDS);
-  const u32 wi = off >> 6, bi = off & 63;
-  const uint4 hdr = p[0];
-  uint4 ch[WM_CHUNKS];
-#pragma unroll
-  for (u32 k = 0; k < WM_CHUNKS; k++) ch[k] = p[1 + k];
-  u64 lo[WM_CHUNKS], hi[WM_CHUNKS];
-#pragma unroll
-  for (u32 k = 0; k < WM_CHUNKS; k++) {
-    lo[k] = ((u64)ch[k].y << 32) | ch[k].x;
-    hi[k] = ((u64)ch[k].w << 32) | ch[k].z;
-  }
-  const u64 mylo = wi == 0 ? lo[0] : (wi == 1 ? lo[1] : lo[2]), myhi = wi == 0 ? hi[0] : (wi == 1 ? hi[1] : hi[2]);
-  const u32 d = (u32)((mylo >> bi) & 1) | ((u32)((myhi >> bi) & 1) << 1);
-  u32 cnt = d == 0 ? hdr.x : (d == 1 ? hdr.y : (d == 2 ? hdr.z : hdr.w));
-  const u64 inv0 = (d & 1) ? 0ull : ~0ull, inv1 = (d & 2) ? 0ull : ~0ull;
-  const u64 part = (1ull << bi) - 1;
-#pragma unroll
-  for (u32 k = 0; k < WM_CHUNKS; k++) {
-    const u64 msk = (k < wi) ? ~0ull : (k == wi ? part : 0ull);
-    cnt += __popcll((lo[k] ^ inv0) & (hi[k] ^ inv1) & msk);
-  }
-  *digit = d;
-  *before = cnt;
-}
-
-// the same for a 16-ary level: one 128-byte block
-__device__ __forceinline__ void wm_access_digit16(const u64 *__restrict__ lvl, u32 pos, u32 *digit, u32 *before) {
-  const u32 blk = pos / WM16_BLOCK_POS, off = pos % WM16_BLOCK_POS;
-  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM16_BLOCK_WORDS);
-  uint4 pl[4];
-#pragma unroll
-  for (u32 b = 0; b < 4; b++) pl[b] = p[4 + b];
-  u32 d = 0;
-#pragma unroll
-  for (u32 b = 0; b < 4; b++) {
-    const u64 word = off < 64 ? (((u64)pl[b].y << 32) | pl[b].x) : (((u64)pl[b].w << 32) | pl[b].z);
-    d |= (u32)((word >> (off & 63)) & 1) << b;
-  }
-  const uint4 h = p[d >> 2];
-  u32 cnt = (d & 3) == 0 ? h.x : ((d & 3) == 1 ? h.y : ((d & 3) == 2 ? h.z : h.w));
-  u64 m0 = ~0ull, m1 = ~0ull;
-#pragma unroll
-  for (u32 b = 0; b < 4; b++) {
-    const u64 inv = ((d >> b) & 1) ? 0ull : ~0ull;
-    m0 &= (((u64)pl[b].y << 32) | pl[b].x) ^ inv;
-    m1 &= (((u64)pl[b].w << 32) | pl[b].z) ^ inv;
-  }
-  const u64 k0 = off >= 64 ? ~0ull : ((1ull << off) - 1), k1 = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
-  *digit = d;
-  *before = cnt + __popcll(m0 & k0) + __popcll(m1 & k1);
-}
-
-// L[i] and LF_map_mod(L[i], i) (include/bwt.h:253-259) for a rank i other than the hidden one
-__device__ __forceinline__ SymNext wm_access_lf(const WmView &wm, const u32 *__restrict__ lf_base, u32 i, u32 e_char,
-                                                u32 e_rank) {
-  u32 q = i, code = 0;
-  for (int l = 0; l < wm.levels; l++) {
-    q = q < wm.max_pos ? q : wm.max_pos;
-    u32 d, before;
-    if (wm.dbits == 4) wm_access_digit16(wm.planes + (u64)l * wm.level_words, q, &d, &before);
-    else wm_access_digit(wm.planes + (u64)l * wm.level_words, q, &d, &before);
-    code = (code << wm.dbits) | d;
-    q = wm.start[l][d] + before;
-  }
-  const u32 c = code + wm.min_sym;
-  u32 k = lf_base[c] + q - (u32)(code == 0 && wm.hidden < i);
-  k += (u32)(k >= e_rank && c == e_char);
-  return SymNext{c, k};
-}
-
 struct InverseParams {
   WmView wm;
   const u32 *lf_tab;
@@ -201,14 +122,13 @@ __global__ void __launch_bounds__(INV_THREADS)
   out[k] = by_rank_pos[lo] + steps;
 }
 
-void sa_batch(Ctx &c, Block &blk, const u32 *d_rank, u32 *d_out, size_t nq) {
-  if (nq == 0) return;
+// which ranks of the block are sampled (a bit per rank) and the samples ordered by rank
+void build_rank_index(Ctx &c, Block &blk, RankIndex &ix) {
   if (blk.n_samp < 1) fail(BWT_HIP_EINVAL, "sa: the block has no samples");
-  build_wavelet(c, blk);
   const size_t ns = (size_t)blk.n_samp, m = (size_t)blk.len();
-  DBuf<u32> bits(c, m / 32 + 1);
-  HIP_CHECK(hipMemsetAsync(bits.get(), 0, (m / 32 + 1) * sizeof(u32), c.stream));
-  hipLaunchKernelGGL(k_mark_samples, dim3(ceil_div(ns, 256)), dim3(256), 0, c.stream, blk.samp_rank.get(), (u32)ns, bits.get());
+  ix.bits = DBuf<u32>(c, m / 32 + 1);
+  HIP_CHECK(hipMemsetAsync(ix.bits.get(), 0, (m / 32 + 1) * sizeof(u32), c.stream));
+  hipLaunchKernelGGL(k_mark_samples, dim3(ceil_div(ns, 256)), dim3(256), 0, c.stream, blk.samp_rank.get(), (u32)ns, ix.bits.get());
   HIP_CHECK(hipGetLastError());
   DBuf<u32> k0(c, ns), k1(c, ns), v0(c, ns), v1(c, ns);
   HIP_CHECK(hipMemcpyAsync(k0.get(), blk.samp_rank.get(), ns * 4, hipMemcpyDeviceToDevice, c.stream));
@@ -217,11 +137,21 @@ void sa_batch(Ctx &c, Block &blk, const u32 *d_rank, u32 *d_out, size_t nq) {
   int bits_needed = 1;
   while (bits_needed < 32 && (m >> bits_needed)) bits_needed++;
   const int cur = radix_sort_u32(c, kk, vv, ns, 0, bits_needed);
+  ix.by_rank = std::move(cur ? k1 : k0);
+  ix.by_rank_pos = std::move(cur ? v1 : v0);
+  ix.ns = (u32)ns;
+}
+
+void sa_batch(Ctx &c, Block &blk, const u32 *d_rank, u32 *d_out, size_t nq) {
+  if (nq == 0) return;
+  build_wavelet(c, blk);
+  RankIndex ix;
+  build_rank_index(c, blk, ix);
   hipLaunchKernelGGL(k_sa_batch, dim3(ceil_div(nq, INV_THREADS)), dim3(INV_THREADS), 0, c.stream, make_view(blk),
-                     blk.wm.lf_base.get(), bits.get(), kk[cur], vv[cur], (u32)ns, (u32)m, (u32)blk.e_char, (u32)blk.e_rank, d_rank,
-                     (u32)nq, d_out);
+                     blk.wm.lf_base.get(), ix.bits.get(), ix.by_rank.get(), ix.by_rank_pos.get(), ix.ns, (u32)blk.len(),
+                     (u32)blk.e_char, (u32)blk.e_rank, d_rank, (u32)nq, d_out);
   HIP_CHECK(hipGetLastError());
-  c.sync();  // the sorted samples die with this scope
+  c.sync();  // the index dies with this scope
 }
 
 }  // namespace bwtamd

@@ -123,4 +123,83 @@ __device__ __forceinline__ u32 wm_lf(const WmView &wm, const u32 *__restrict__ l
   return k - (u32)(code == 0 && wm.hidden < i);
 }
 
+struct SymNext {
+  u32 sym;   // L[i]
+  u32 next;  // LF_map_mod(L[i], i), relative to the block's first rank
+};
+
+// digit at `pos` of a 4-ary level and its occurrences before pos: one 64-byte block
+__device__ __forceinline__ void wm_access_digit(const u64 *__restrict__ lvl, u32 pos, u32 *digit, u32 *before) {
+  const u32 blk = pos / WM_BLOCK_POS, off = pos - blk * WM_BLOCK_POS;
+  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM_BLOCK_WORDS);
+  const u32 wi = off >> 6, bi = off & 63;
+  const uint4 hdr = p[0];
+  uint4 ch[WM_CHUNKS];
+#pragma unroll
+  for (u32 k = 0; k < WM_CHUNKS; k++) ch[k] = p[1 + k];
+  u64 lo[WM_CHUNKS], hi[WM_CHUNKS];
+#pragma unroll
+  for (u32 k = 0; k < WM_CHUNKS; k++) {
+    lo[k] = ((u64)ch[k].y << 32) | ch[k].x;
+    hi[k] = ((u64)ch[k].w << 32) | ch[k].z;
+  }
+  const u64 mylo = wi == 0 ? lo[0] : (wi == 1 ? lo[1] : lo[2]), myhi = wi == 0 ? hi[0] : (wi == 1 ? hi[1] : hi[2]);
+  const u32 d = (u32)((mylo >> bi) & 1) | ((u32)((myhi >> bi) & 1) << 1);
+  u32 cnt = d == 0 ? hdr.x : (d == 1 ? hdr.y : (d == 2 ? hdr.z : hdr.w));
+  const u64 inv0 = (d & 1) ? 0ull : ~0ull, inv1 = (d & 2) ? 0ull : ~0ull;
+  const u64 part = (1ull << bi) - 1;
+#pragma unroll
+  for (u32 k = 0; k < WM_CHUNKS; k++) {
+    const u64 msk = (k < wi) ? ~0ull : (k == wi ? part : 0ull);
+    cnt += __popcll((lo[k] ^ inv0) & (hi[k] ^ inv1) & msk);
+  }
+  *digit = d;
+  *before = cnt;
+}
+
+// the same for a 16-ary level: one 128-byte block
+__device__ __forceinline__ void wm_access_digit16(const u64 *__restrict__ lvl, u32 pos, u32 *digit, u32 *before) {
+  const u32 blk = pos / WM16_BLOCK_POS, off = pos % WM16_BLOCK_POS;
+  const uint4 *p = reinterpret_cast<const uint4 *>(lvl + (u64)blk * WM16_BLOCK_WORDS);
+  uint4 pl[4];
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) pl[b] = p[4 + b];
+  u32 d = 0;
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) {
+    const u64 word = off < 64 ? (((u64)pl[b].y << 32) | pl[b].x) : (((u64)pl[b].w << 32) | pl[b].z);
+    d |= (u32)((word >> (off & 63)) & 1) << b;
+  }
+  const uint4 h = p[d >> 2];
+  u32 cnt = (d & 3) == 0 ? h.x : ((d & 3) == 1 ? h.y : ((d & 3) == 2 ? h.z : h.w));
+  u64 m0 = ~0ull, m1 = ~0ull;
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) {
+    const u64 inv = ((d >> b) & 1) ? 0ull : ~0ull;
+    m0 &= (((u64)pl[b].y << 32) | pl[b].x) ^ inv;
+    m1 &= (((u64)pl[b].w << 32) | pl[b].z) ^ inv;
+  }
+  const u64 k0 = off >= 64 ? ~0ull : ((1ull << off) - 1), k1 = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+  *digit = d;
+  *before = cnt + __popcll(m0 & k0) + __popcll(m1 & k1);
+}
+
+// L[i] and LF_map_mod(L[i], i) (include/bwt.h:253-259) for a rank i other than the hidden one
+__device__ __forceinline__ SymNext wm_access_lf(const WmView &wm, const u32 *__restrict__ lf_base, u32 i, u32 e_char,
+                                                u32 e_rank) {
+  u32 q = i, code = 0;
+  for (int l = 0; l < wm.levels; l++) {
+    q = q < wm.max_pos ? q : wm.max_pos;
+    u32 d, before;
+    if (wm.dbits == 4) wm_access_digit16(wm.planes + (u64)l * wm.level_words, q, &d, &before);
+    else wm_access_digit(wm.planes + (u64)l * wm.level_words, q, &d, &before);
+    code = (code << wm.dbits) | d;
+    q = wm.start[l][d] + before;
+  }
+  const u32 c = code + wm.min_sym;
+  u32 k = lf_base[c] + q - (u32)(code == 0 && wm.hidden < i);
+  k += (u32)(k >= e_rank && c == e_char);
+  return SymNext{c, k};
+}
+
 }  // namespace bwtamd

@@ -183,3 +183,32 @@ def test_n3_1e9_one_leaf_wide_route(ctx):
     assert h8(two.L) == f1
     two.free()
     ctx.trim()
+
+
+def test_config4_repetitive_4_6e8(ctx):
+    """Config 4 at full size: 100 copies of a 4.6e6-symbol genome with 0.1 % substitutions (LCPs of thousands),
+    two leaves and one merge.  The reference's comparison sort does not finish this text in reasonable time, so:
+    L a permutation of T, L[rank] = T[pos-1] at every sample, L decoded back to the text on the device, and the same
+    L from four leaves (other windows, other chains)."""
+    from oracle import gen_repetitive
+    T = gen_repetitive(4600000, 100, 0.001, seed=43, sigma=4)
+    n = len(T)
+    ctx.set_text(T)
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    blk = ctx.pmbwt(n // 2 + 1, 1000000)
+    deferred = launches(ctx, "gap_chains_deferred")
+    ctx.set_timing(0)
+    assert deferred == 1  # the chains' heads came from the left block's sampled suffix array
+    assert blk.ibwt_mismatches() == 0
+    L = blk.L
+    r, p = blk.samples()
+    assert (np.bincount(L, minlength=5) == np.bincount(T, minlength=5)).all()
+    assert L[blk.s_rank] == 0 and p[0] == 0 and p[-1] == n - 1
+    assert (L[r] == T[p - 1]).all()
+    fnv = h8(L)
+    blk.free()
+    b4 = ctx.pmbwt(n // 4 + 1, 1000000)
+    assert h8(b4.L) == fnv
+    b4.free()
+    ctx.trim()
