@@ -323,8 +323,9 @@ struct RefineTileParams {
   u32 *sa;
   u64 a, b, e, n, h_exact, h;
   u32 *overflow, *fail;
-  u32 *nslot, *npos, *ngrp;  // per list entry, in the new order: rank index, position, new group name
-  u8 *ntied;                 // bit 0: still tied; bit 1: the group name changed (the inverse array needs it)
+  u32 *npos, *ngrp;  // per list entry, in the new order: position, new group name (the rank indices stay as they are)
+  u8 *ntied;         // bit 0: still tied; bit 1: the group name changed (the inverse array needs it)
+  u32 *wg_tied;      // per workgroup (zeroed by the caller): its entries that are still tied
 };
 
 __global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) {
@@ -440,6 +441,7 @@ __global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) 
   tmx[tid] = block_scan_incl<OpMax>(mx, scan_s, &tot);
   __syncthreads();
   run = tid ? tmx[tid - 1] : 0u;
+  u32 n_tied = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const u32 i = tid * 4 + j;
@@ -447,14 +449,47 @@ __global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) 
     if (i >= lo && i < hi) {
       const bool head = v[j] != 0;
       const bool next_head = (i + 1 == ge_s[gs_s[i]]) || new_head(i + 1);
-      const u32 s = Ds[i], p = A[i];
-      P.sa[s] = p;
-      P.nslot[base + i] = s;
+      const bool tied = !(head && next_head);
+      const u32 p = A[i];
+      if (!tied) P.sa[Ds[i]] = p;  // placed for good; a position that is still tied is written by a later round
       P.npos[base + i] = p;
       const u32 name = Ds[run - 1];  // the new group is named by the rank of its first member, as the old one was
       P.ngrp[base + i] = name;
-      P.ntied[base + i] = (u8)((u32)!(head && next_head) | ((u32)(name != Ds[gs_s[i]]) << 1));
+      P.ntied[base + i] = (u8)((u32)tied | ((u32)(name != Ds[gs_s[i]]) << 1));
+      n_tied += tied;
     }
+  }
+  u32 all_tied;
+  block_scan_incl<OpSum>(n_tied, scan_s, &all_tied);
+  if (tid == 0) P.wg_tied[blockIdx.x] = all_tied;
+}
+
+// *out = sum of v[0:n), one workgroup
+__global__ void __launch_bounds__(1024) k_sum_u32(const u32 *__restrict__ v, u32 n, u32 *__restrict__ out) {
+  __shared__ u32 scan_s[17];
+  u32 mine = 0;
+  for (u32 i = threadIdx.x; i < n; i += 1024) mine += v[i];
+  u32 tot;
+  block_scan_incl<OpSum>(mine, scan_s, &tot);
+  if (threadIdx.x == 0) *out = tot;
+}
+
+// after a round that keeps its list: the inverse array takes the new names (four entries per thread)
+__global__ void k_isa_update(const u8 *__restrict__ flags, const u32 *__restrict__ npos, const u32 *__restrict__ ngrp, u32 M,
+                             u32 a, u32 *__restrict__ isa) {
+  const u32 i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 + 4 <= M) {
+    const u32 f = *reinterpret_cast<const u32 *>(flags + i0);
+    if (f & 0x02020202u) {
+      const uint4 p4 = *reinterpret_cast<const uint4 *>(npos + i0), g4 = *reinterpret_cast<const uint4 *>(ngrp + i0);
+      if (f & 0x00000002u) isa[p4.x - a] = g4.x;
+      if (f & 0x00000200u) isa[p4.y - a] = g4.y;
+      if (f & 0x00020000u) isa[p4.z - a] = g4.z;
+      if (f & 0x02000000u) isa[p4.w - a] = g4.w;
+    }
+  } else {
+    for (u32 i = i0; i < M; i++)
+      if (flags[i] & 2u) isa[npos[i] - a] = ngrp[i];
   }
 }
 
@@ -1394,31 +1429,50 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     }
     if (!text_round && tile_rounds) {
       // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
-      DBuf<u32> ts(c, M), tp(c, M), tg(c, M);
+      DBuf<u32> tp(c, M), tg(c, M);
       DBuf<u8> tt(c, M);
+      const u32 n_wg = ceil_div(M, RT_TILE);
+      DBuf<u32> wg_tied(c, n_wg);
       HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+      HIP_CHECK(hipMemsetAsync(wg_tied.get(), 0, (size_t)n_wg * sizeof(u32), c.stream));
       RefineTileParams P{wl_slot, wl_pos, wl_grp, M, isa.get(), sa_w, (u64)a, (u64)b, (u64)e, (u64)c.n, h_exact, h,
-                         d_overflow, d_fail, ts.get(), tp.get(), tg.get(), tt.get()};
+                         d_overflow, d_fail, tp.get(), tg.get(), tt.get(), wg_tied.get()};
       {
         KernelTimer kt(c, "refine:k_refine_tile", (double)M * 25);
-        hipLaunchKernelGGL(k_refine_tile, dim3(ceil_div(M, RT_TILE)), dim3(RT_THREADS), 0, c.stream, P);
+        hipLaunchKernelGGL(k_refine_tile, dim3(n_wg), dim3(RT_THREADS), 0, c.stream, P);
         HIP_CHECK(hipGetLastError());
       }
-      if (read_u32(c, d_fail) == 0) {
-        DBuf<u32> ns(c, M), np(c, M), ng(c, M);
-        scan_generic<u32, SumU32>(c, M, TiedIn{tt.get()},
-                                  RefineCompactOut{tt.get(), ts.get(), tp.get(), tg.get(), isa.get(), (u32)a, ns.get(), np.get(), ng.get(),
-                                                   d_total, M});
-        M = read_u32(c, d_total);
-        nl_slot = std::move(ns);
-        nl_pos = std::move(np);
-        nl_grp = std::move(ng);
-        wl_slot = nl_slot.get();
+      hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, c.stream, (const u32 *)wg_tied.get(), n_wg, d_total);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, c.d_scalars + 8, 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      if (c.h_scalars[10] == 0) {  // d_fail
+        const bool overflow = c.h_scalars[9] != 0;
+        const u64 still = c.h_scalars[8];  // d_total
+        if (!overflow && still * 100 > (u64)M * 85) {
+          // Nearly all entries are still tied: the list stays as it is (the placed entries are groups of one from now
+          // on and cost the next round a look-up each), only the inverse array takes the new names.
+          hipLaunchKernelGGL(k_isa_update, dim3(ceil_div(ceil_div(M, 4), 256)), dim3(256), 0, c.stream, (const u8 *)tt.get(),
+                             (const u32 *)tp.get(), (const u32 *)tg.get(), M, (u32)a, isa.get());
+          HIP_CHECK(hipGetLastError());
+        } else if (!overflow) {
+          DBuf<u32> ns(c, M), np(c, M), ng(c, M);
+          scan_generic<u32, SumU32>(c, M, TiedIn{tt.get()},
+                                    RefineCompactOut{tt.get(), wl_slot, tp.get(), tg.get(), isa.get(), (u32)a, ns.get(), np.get(), ng.get(),
+                                                     d_total, M});
+          M = read_u32(c, d_total);
+          nl_slot = std::move(ns);
+          tp = std::move(np);
+          tg = std::move(ng);
+          wl_slot = nl_slot.get();
+        }
+        nl_pos = std::move(tp);
+        nl_grp = std::move(tg);
         wl_pos = nl_pos.get();
         wl_grp = nl_grp.get();
         h = 2 * h;
         round++;
-        if (read_u32(c, d_overflow)) return false;
+        if (overflow) return false;
         if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
         continue;
       }
