@@ -101,6 +101,8 @@ struct Ctx {
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
   // the left block's suffix array (gap.hip); off: they restart from further and further right instead
   bool defer_chains = true;
+  // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
+  bool repeat_probe = true;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;
@@ -274,7 +276,8 @@ struct BucketState {
   u32 max_bucket = 0;  // elements of the largest bucket
   bool pending = false;
 };
-int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs);
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs,
+                          bool try_buckets = true);
 void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs);
 void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket, int bbits = 16);
 int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,

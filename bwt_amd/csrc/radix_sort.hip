@@ -1103,14 +1103,14 @@ void bucket_sort_in_place(Ctx &c, u64 *e, size_t n, const BucketState &bs) {
 // bs: if not null and the bucket route applies, the sort stops after the passes on the top 16 bits and
 // hands the buckets over (bs->pending); the caller finishes them (bucket_sort_in_place, or a kernel of its
 // own that consumes the sorted buckets straight from LDS).
-int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs) {
+int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs, bool try_buckets) {
   if (n == 0) return 0;
   if (begin_bit % 8 != 0 || begin_bit < 32 || begin_bit >= 64 || text.pbits <= 0 || text.pbits > 31 ||
       (n - 1) >> text.pbits)
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad packed layout (begin_bit %d, pbits %d, n %zu)", begin_bit, text.pbits, n);
-  if (begin_bit < 48 && n >= c.bucket_min_n && buckets_look_even(c, text, n)) {
+  if (try_buckets && begin_bit < 48 && n >= c.bucket_min_n && buckets_look_even(c, text, n)) {
     // top 16 bits by two passes (the first one reverse-stable from the text, as always), the rest per bucket
-    const int cur = leaf_sort_text_packed(c, elems, n, 48, text, nullptr);
+    const int cur = leaf_sort_text_packed(c, elems, n, 48, text, nullptr, false);
     BucketState local;
     BucketState &st = bs ? *bs : local;
     if (bucket_bounds(c, elems[cur], n, st.start, &st.max_bucket)) {

@@ -1227,6 +1227,56 @@ static int bits_for(u64 x) {  // bits needed to hold values 0..x
   return b;
 }
 
+// Does the window hold long repeats?  A bucket route or the direct pass would do their work and then give up on
+// such a text, so large windows are probed first: RP_SAMPLES positions, one in every stretch of N / RP_SAMPLES,
+// hashed over their next 64 symbols into a table; two positions with the same 64 symbols count as a collision.  A
+// text without long repeats has none (64 symbols of even a two-letter alphabet), a text whose repeats would defeat
+// the direct pass -- copies of long stretches -- has many: the copies' positions collide whenever both are sampled.
+constexpr u32 RP_SAMPLES = 1u << 18;
+constexpr u32 RP_TABLE = 1u << 20;
+
+__global__ void k_repeat_probe(const u8 *__restrict__ T, u64 n, u64 a, u64 N, u64 stride, unsigned long long *__restrict__ table,
+                               u32 *__restrict__ collisions) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= RP_SAMPLES) return;
+  u64 x = (t + 1) * 0x9E3779B97F4A7C15ull;  // the position's place inside its stretch
+  x ^= x >> 29;
+  const u64 p = a + t * stride + (x % stride);
+  if (p + 64 > n || p >= a + N) return;
+  u64 h = 0xCBF29CE484222325ull;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u64 w;
+    __builtin_memcpy(&w, T + p + 8 * k, 8);
+    h = (h ^ w) * 0x100000001B3ull;
+    h ^= h >> 32;
+  }
+  h |= 1ull;  // 0 marks an empty slot
+  u32 slot = (u32)(h >> 40) & (RP_TABLE - 1);
+  for (u32 probes = 0; probes < RP_TABLE; probes++) {
+    const unsigned long long old = atomicCAS(&table[slot], 0ull, (unsigned long long)h);
+    if (old == 0ull) return;
+    if (old == h) {
+      atomicAdd(collisions, 1u);
+      return;
+    }
+    slot = (slot + 1) & (RP_TABLE - 1);
+  }
+}
+
+static bool window_has_long_repeats(Ctx &c, i64 a, u64 N) {
+  if (N < c.bucket_min_n || N < (u64)RP_SAMPLES * 64 || !c.repeat_probe) return false;
+  KernelTimer kt(c, "leaf:k_repeat_probe", (double)RP_SAMPLES * 64);
+  DBuf<unsigned long long> table(c, RP_TABLE);
+  u32 *d_count = c.d_scalars + 13;
+  HIP_CHECK(hipMemsetAsync(table.get(), 0, (size_t)RP_TABLE * 8, c.stream));
+  HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
+  hipLaunchKernelGGL(k_repeat_probe, dim3(RP_SAMPLES / 256), dim3(256), 0, c.stream, c.T, (u64)c.n, (u64)a, N, N / RP_SAMPLES,
+                     table.get(), d_count);
+  HIP_CHECK(hipGetLastError());
+  return read_u32(c, d_count) >= 8;
+}
+
 // Layout of the round-0 key (TextKeys): coding, number of symbols K0, pairs or packed elements.  Every 8
 // sorted key bits cost one radix pass over the whole window; fewer symbols leave more suffixes tied for the
 // refinement, which only touches the tied ones.
@@ -1315,7 +1365,7 @@ static void launch_bucket_emit(Ctx &c, const LeafEmit<V> &em, u32 n_buckets, u32
 template <class View>
 static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_mask, View v, u32 *sa_w, u64 *e_w,
                           u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out, BucketState *bs = nullptr,
-                          const TextKeys *tk = nullptr) {
+                          const TextKeys *tk = nullptr, bool skip_direct = false) {
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
@@ -1323,7 +1373,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   HIP_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(u32), c.stream));
   DBuf<u32> res;
   if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
-  {
+  if (!skip_direct) {
     // First try to finish in one pass: ties ordered by direct comparison and everything emitted at once.
     // It gives up as a whole on large tie groups or long common prefixes (repetitive texts); what it wrote
     // until then is overwritten by the general path below.
@@ -1697,9 +1747,12 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   const int begin_bit = low_bit & ~7;  // whole digits; the extra low bits are zero padding
   const int passes = (64 - begin_bit) / 8;
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
+  // a text with long repeats goes straight to the plain passes and the refinement rounds
+  const bool repeats = window_has_long_repeats(c, a, N);
   // windows the packed elements cannot index: lean elements up to 2^31 suffixes, wide ones beyond
-  if ((!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
-  if ((!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
+  if (!repeats && (!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1)
+    return true;
+  if (!repeats && (!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
     DBuf<u64> eb0(c, N), eb1(c, N);
@@ -1713,13 +1766,13 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
       // element (16); every further pass reads the element for its histogram (8) and moves it (16).  The
       // bucket route stops after the second pass.
       Phase ph(c, "leaf_radix_sort", 0);
-      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, &bs);
+      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, repeats ? nullptr : &bs, !repeats);
       const int done = bs.pending ? 2 : passes;
       ph.add_work((double)N * (done <= 1 ? 10 : 11 + 17 + (done - 2) * 24));
     }
     PackedView v{el[cur], nullptr, (u32)a, (u32)((1ull << kp.pbits) - 1), kp.pbits};
     return finish_window<PackedView>(c, a, b, e, N, K0, sym_mask, v, nullptr, el[cur], (u32 *)el[cur ^ 1], grp.get(), E,
-                                     sa_out, &bs, &tk);
+                                     sa_out, &bs, &tk, repeats);
   }
   const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
   DBuf<u64> kb0(c, stride), kb1(c, stride);
@@ -1733,7 +1786,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   }
   PairsView v{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride, vals[cur]};
   return finish_window<PairsView>(c, a, b, e, N, K0, sym_mask, v, vals[cur], nullptr, (u32 *)keys[cur ^ 1],
-                                  vals[cur ^ 1], E, sa_out);
+                                  vals[cur ^ 1], E, sa_out, nullptr, nullptr, repeats);
 }
 
 static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *sa_out) {

@@ -60,14 +60,16 @@ def main():
     ctx.reset_timers()
     same_as_oracle(ctx, T, 4, 70000, 1000)
     assert launches(ctx, "leaf:k_bucket_emit") > 0 and launches(ctx, "leaf:k_bucket_sort") > 0
-    # a long skewed text: a sample of the window already says that the buckets will not fit
+    # a long skewed text: the probe for long repeats (runs of the frequent symbol) or, without it, a sample of the
+    # window already says that the bucket route will not do
     n = 70000000
     T = np.concatenate([np.where(rng.random(n) < 0.9, 1, rng.integers(1, 5, n)).astype(np.uint8),
                         np.zeros(1, dtype=np.uint8)])
     ctx.set_text(T)
     ctx.reset_timers()
     blk = ctx.pmbwt(len(T), 4000)
-    assert launches(ctx, "leaf:k_bucket_histogram") > 0 and launches(ctx, "leaf:k_bucket_bounds") == 0
+    assert launches(ctx, "leaf:k_repeat_probe") + launches(ctx, "leaf:k_bucket_histogram") > 0
+    assert launches(ctx, "leaf:k_bucket_bounds") == 0 and launches(ctx, "leaf:k_bucket_emit") == 0
     L = blk.L
     assert (np.bincount(L, minlength=5) == np.bincount(T, minlength=5)).all()
     r, p = blk.samples()

@@ -197,9 +197,10 @@ def test_config4_repetitive_4_6e8(ctx):
     ctx.set_timing(2)
     ctx.reset_timers()
     blk = ctx.pmbwt(n // 2 + 1, 1000000)
-    deferred = launches(ctx, "gap_chains_deferred")
+    deferred, probes, emits = launches(ctx, "gap_chains_deferred"), launches(ctx, "leaf:k_repeat_probe"), launches(ctx, "leaf:k_bucket_emit")
     ctx.set_timing(0)
     assert deferred == 1  # the chains' heads came from the left block's sampled suffix array
+    assert probes == 2 and emits == 0  # both leaves were probed and went straight to the refinement rounds
     assert blk.ibwt_mismatches() == 0
     L = blk.L
     r, p = blk.samples()
