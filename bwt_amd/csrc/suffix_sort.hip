@@ -1749,10 +1749,12 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
   // a text with long repeats goes straight to the plain passes and the refinement rounds
   const bool repeats = window_has_long_repeats(c, a, N);
-  // windows the packed elements cannot index: lean elements up to 2^31 suffixes, wide ones beyond
-  if (!repeats && (!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1)
+  // Windows the packed elements cannot index: lean elements up to 2^31 suffixes, wide ones beyond.  These routes
+  // settle every tie on the text itself, so they sort the leaf's own suffixes and no window slack.
+  const u64 NL = (u64)(b - a);
+  if (!repeats && (!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1)
     return true;
-  if (!repeats && (!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, e, N, min_sym, span, E, sa_out) == 1) return true;
+  if (!repeats && (!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
     DBuf<u64> eb0(c, N), eb1(c, N);

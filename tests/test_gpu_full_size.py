@@ -161,7 +161,7 @@ def test_config3_n3_1e9_eight_leaves(ctx):
 def test_n3_1e9_two_leaves_lean_route(ctx):
     """bench.py's default on one GPU: 3.1e9 symbols as two leaves of 1.55e9 suffixes (more than 2^29: the lean
     bucket route, 2^18 buckets) and one merge; against the same tree sorted as (key, position) pairs."""
-    _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=7,lean", "leaf:bucket_emit_items=7,slack,lean"], 8)
+    _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=7,lean"], 8)
     ctx.trim()
 
 
