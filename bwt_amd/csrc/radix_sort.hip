@@ -448,15 +448,20 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     __syncthreads();
     u64 mine[RS_ITEMS];
     tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
+    // Where the order inside a digit is free (ANY_ORDER) a thread ranks the keys it rolled itself: no exchange.
+    // (Only whole tiles: the ranking's bookkeeping of a short tile assumes the slots of the exchange.)
+    const bool direct = ANY_ORDER && full;
+    if (!direct) {
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) ex[tid * RS_ITEMS + (j ^ ((tid >> 2) & 7))] = mine[j];
-    __syncthreads();
+      for (int j = 0; j < RS_ITEMS; j++) ex[tid * RS_ITEMS + (j ^ ((tid >> 2) & 7))] = mine[j];
+      __syncthreads();
+    }
     const u32 pos0 = (u32)(tk.a + tile0);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
-      u32 idx = wbase + r * 64 + lane;
+      u32 idx = direct ? tid * RS_ITEMS + r : wbase + r * 64 + lane;
       bool valid = idx < tile_n;
-      u64 k = valid ? ex[(idx & ~7u) | ((idx & 7) ^ ((idx >> 5) & 7))] : 0ull;
+      u64 k = direct ? mine[r] : (valid ? ex[(idx & ~7u) | ((idx & 7) ^ ((idx >> 5) & 7))] : 0ull);
       if constexpr (HAS_VALS) {
         key[r] = (K)k;
         val[r] = pos0 + idx;
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
       }
     }
-    __syncthreads();  // the exchange area becomes the counters
+    if (!direct) __syncthreads();  // the exchange area becomes the counters
   } else if constexpr (SPLIT) {
     const u32 *lo = reinterpret_cast<const u32 *>(kin) + tile0;
     const u32 *hi = lo + stride;
