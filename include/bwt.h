@@ -38,6 +38,8 @@
 #include "suffix_array.h"
 #include "wavelet_matrix.h"
 #include "sampled_suffix_array.h"
+#include "succinct_bit_vector.h"
+#include "gap_array.h"
 
 namespace bwt {
 

@@ -55,4 +55,12 @@ namespace bwt {
     std::sort(first, last, lt);
   }
 
+  /* every element strictly below its successor (include/task_parallel_sort.h:146-153) */
+  template<typename T, typename Compare>
+  int check_sorted(T * a, T * e, const Compare & lt) {
+    for (idx_t i = 0; i + 1 < (idx_t)(e - a); i++)
+      if (!check(lt(a[i], a[i + 1]))) return 0;
+    return 1;
+  }
+
 }

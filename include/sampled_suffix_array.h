@@ -92,21 +92,20 @@ namespace bwt {
 
     idx_t hash(idx_t r) { return r & (sz - 1); }
 
-    /* returns 1 if (rank,pos) was inserted, 0 if rank was already there */
+    /* returns 1 if (rank,pos) was inserted, 0 if rank was already there.  May be called from several threads
+       at once (include/sampled_suffix_array.h:183-211 there): the key slot is claimed with a compare-and-swap. */
     int put(idx_t rank, idx_t pos) {
       assert(begin == 0);
-      stat.start(ts_event_ssa_put);
       idx_t h = hash(rank);
       for (idx_t k = 0; k < sz; k++) {
         ssa_entry & e = a[(h + k) & (sz - 1)];
-        if (e.rank == rank) { stat.end(ts_event_ssa_put); return 0; }
-        if (e.rank == -1) {
-          e.rank = rank;
+        idx_t seen = __sync_val_compare_and_swap(&e.rank, (idx_t)-1, rank);
+        if (seen == -1) {
           e.pos = pos;
-          n++;
-          stat.end(ts_event_ssa_put);
+          __sync_fetch_and_add(&n, (idx_t)1);
           return 1;
         }
+        if (seen == rank) return 0;
       }
       check(0); /* table full */
       return 0;
