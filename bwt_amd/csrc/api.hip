@@ -88,6 +88,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_FORCE_WIDE")) c.force_wide = atoi(v);
   if (const char *v = getenv("BWT_HIP_WIDE_BBITS")) c.wide_bbits = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_ANY")) c.lean_any_order = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_GAP_LEAN")) c.gap_lean = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_DEFER_CHAINS")) c.defer_chains = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current

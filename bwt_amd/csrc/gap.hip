@@ -327,6 +327,46 @@ __global__ void __launch_bounds__(GH_THREADS)
     if (base + j <= m) S[base + j] = hist[gh_slot(j)];
 }
 
+// The same from the two-pass grouping that keeps neither digit (gap_sort_lean): a bucket's values are the 16-bit
+// words [start[bucket], start[bucket + 1]), each the low bits of a g whose high bits are the bucket's number.
+__global__ void __launch_bounds__(GH_THREADS)
+    k_bucket_prefix16(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 *__restrict__ S) {
+  __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x;
+  const u32 width = 1u << low;
+  const u32 bucket = blockIdx.x;
+  for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
+  __syncthreads();
+  const u32 lo = start[bucket], hi = start[bucket + 1];
+  const u64 base = (u64)bucket << low;
+  for (u32 i0 = lo + tid; i0 < hi; i0 += 8 * GH_THREADS) {
+    u32 g[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 i = i0 + k * GH_THREADS;
+      g[k] = i < hi ? (u32)keys[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (g[k] != 0xFFFFFFFFu && base + g[k] <= m) atomicAdd(&hist[gh_slot(g[k])], 1u);  // fillers (m+1) are skipped
+  }
+  __syncthreads();
+  const u32 per = (width + GH_THREADS - 1) / GH_THREADS;
+  const u32 j0 = tid * per;
+  u32 mine = 0;
+  for (u32 j = j0; j < j0 + per && j < width; j++) mine += hist[gh_slot(j)];
+  u32 all;
+  u32 run = lo + block_scan_incl<OpSum>(mine, scan_s, &all) - mine;
+  for (u32 j = j0; j < j0 + per && j < width; j++) {
+    run += hist[gh_slot(j)];
+    hist[gh_slot(j)] = run;
+  }
+  __syncthreads();
+  for (u32 j = tid; j < width; j += GH_THREADS)
+    if (base + j <= m) S[base + j] = hist[gh_slot(j)];
+}
+
 static int bits_for(u64 x) {
   int b = 1;
   while (b < 64 && (x >> b)) b++;
@@ -428,8 +468,22 @@ void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S) {
   const int bits = bits_for(m + 1);
   const int low = bits < GH_LOW_MAX ? bits : GH_LOW_MAX;
   const int passes = (bits - low + 7) / 8;
-  Phase ph(c, "gap_histogram", (double)total * (passes * 12 + 4) + (double)(m + 1) * 4);
   u32 *keys[2] = {g0, g1};
+  const u32 n_buckets = (u32)(((m + 1) + ((u64)1 << low) - 1) >> low);
+  const int high = bits - low;
+  if (total > 0 && high > 8 && high <= 18 && low == GH_LOW_MAX && c.gap_lean) {
+    // two passes that keep neither digit; the second leaves 16-bit bucket-local values and the buckets' bounds
+    const int b2 = (high + 1) / 2, b1 = high - b2;
+    Phase ph(c, "gap_histogram", (double)total * (12 + 10 + 2) + (double)(m + 1) * 4);
+    DBuf<u32> start(c, ((size_t)1 << high) + 1);
+    gap_sort_lean(c, keys, total, low, b1, b2, start.get());
+    KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 2 + (double)(m + 1) * 4);
+    hipLaunchKernelGGL(k_bucket_prefix16, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, reinterpret_cast<const u16 *>(keys[0]),
+                       (const u32 *)start.get(), low, (u32)m, S);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  Phase ph(c, "gap_histogram", (double)total * (passes * 12 + 4) + (double)(m + 1) * 4);
   u32 *vals[2] = {nullptr, nullptr};
   int cur = 0;
   if (total > 0) {
@@ -437,7 +491,6 @@ void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S) {
     cur = radix_sort_u32(c, keys, vals, total, low, bits, 2);
     c.sort_tag = "";
   }
-  const u32 n_buckets = (u32)(((m + 1) + ((u64)1 << low) - 1) >> low);
   KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 4 + (double)(m + 1) * 4);
   hipLaunchKernelGGL(k_bucket_prefix, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, keys[cur], (u32)total, low, (u32)m,
                      S);

@@ -98,6 +98,7 @@ struct Ctx {
   int force_wide = 0;
   int wide_bbits = 0;
   bool lean_any_order = true;
+  bool gap_lean = true;  // the gap histogram's grouping in two passes that keep neither digit (gap_sort_lean)
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
   // the left block's suffix array (gap.hip); off: they restart from further and further right instead
   bool defer_chains = true;
@@ -286,6 +287,10 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
 // index = d2 << b1 | d1).  Returns the buffer with the result, or -1 if a bucket holds more than cap elements.
 int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
+// The gap histogram's grouping: the values of keys[0] grouped by their bits [low, low + b1 + b2), in two passes
+// that keep neither digit; afterwards keys[0] holds the values' low `low` bits as 16-bit words, bucket k of them
+// at [start[k], start[k+1]) (start: 2^(b1+b2) + 1 entries).
+void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start);
 
 // ---------------------------------------------------------------------------
 // a partial BWT resident on the device (include/bwt.h:122-149 of the reference)

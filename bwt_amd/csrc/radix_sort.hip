@@ -264,7 +264,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
                                                 u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
-                                                u32 lean_tile0 = 0) {
+                                                u32 lean_tile0 = 0, u32 narrow_mask = 0) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -378,7 +378,14 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
           // position field; the element proper has its window index there
           if (lean_posmask) k = (K)(((u64)k & ~(u64)lean_posmask) | (u64)(lean_tile0 + ((u32)k & (u32)(RS_TILE - 1))));
         }
-        kout[dst] = k;
+        if constexpr (sizeof(K) == 4 && !HAS_VALS) {
+          // last pass of a sort whose higher key bits are known from where a key lies: only the low bits go out, as
+          // 16-bit words (the output array is then an array of those)
+          if (narrow_mask) reinterpret_cast<u16 *>(kout)[dst] = (u16)((u32)k & narrow_mask);
+          else kout[dst] = k;
+        } else {
+          kout[dst] = k;
+        }
         if constexpr (REVERSE && sizeof(K) == 8) {  // the text pass: the next pass's digits on the side
           if (next_digits) next_digits[dst] = (u8)((u64)k >> next_shift);
         }
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
                  u32 nblk, TextKeys tk, u32 stride, const u8 *__restrict__ side_in = nullptr,
-                 u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr) {
+                 u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr, u32 narrow_mask = 0) {
   static_assert(!SIDE || (sizeof(K) == 8 && !HAS_VALS && !SPLIT), "side bytes go with 8-byte keys-only elements");
   u8 sd[RS_ITEMS];
   static_assert(!SPLIT || sizeof(K) == 8, "only 64-bit keys are split");
@@ -527,11 +534,11 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                              lean_posmask, (u32)tile0);
+                                              lean_posmask, (u32)tile0, narrow_mask);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                               lean_posmask, (u32)tile0);
+                                               lean_posmask, (u32)tile0, narrow_mask);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -1040,6 +1047,65 @@ static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk
                      (const u32 *)nullptr, out, (u32 *)nullptr, n, shift, mask, counts, nblk2, none, 0u, (const u8 *)nullptr,
                      (u8 *)nullptr, tmap);
   HIP_CHECK(hipGetLastError());
+}
+
+// The gap histogram's sort with the same device (gap.hip): 32-bit values grouped by their bits [low, low + b1 + b2).
+// The first pass sorts on the lower b1 of those bits, the second on the upper b2 over tiles that follow the first
+// pass's regions; neither needs a stable order (the buckets are only counted), and the second writes just the low
+// `low` bits of a value, as 16-bit words: bucket (d2, d1) = the words [start[d2 << b1 | d1], start[.. + 1]) of the
+// result, which is in keys[0] (keys[1] is scratch).  start: 2^(b1+b2) + 1 entries.
+template <int DB1, int DB2>
+static void gap_sort_lean_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start) {
+  const u32 nblk = ceil_div(n, RS_TILE);
+  const u32 nd1 = 1u << b1, n_buckets = 1u << (b1 + b2);
+  const u32 nblk2 = nblk + nd1 + 1;
+  DBuf<u32> counts(c, (size_t)512 * nblk2);
+  DBuf<u32> tfirst(c, nd1 + 1);
+  DBuf<uint2> tmap(c, nblk2);
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  {
+    KernelTimer kt(c, "gap:k_rs_hist_u32", (double)n * 4);
+    hipLaunchKernelGGL((k_rs_hist<u32, 2, false, DB1>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u32 *)keys[0], n, low,
+                       nd1 - 1, counts.get(), nblk, none, (const uint2 *)nullptr);
+    HIP_CHECK(hipGetLastError());
+  }
+  scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)(1 << DB1) * nblk, nullptr);
+  {
+    KernelTimer kt(c, "gap:k_rs_scatter_u32_keys", (double)n * 8);
+    hipLaunchKernelGGL((k_rs_scatter<u32, false, 2, false, false, true, false, DB1>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                       (const u32 *)keys[0], (const u32 *)nullptr, keys[1], (u32 *)nullptr, n, low, nd1 - 1, counts.get(), nblk, none, 0u,
+                       (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr, 0u);
+    HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)n, tfirst.get(),
+                     tmap.get(), nblk2);
+  HIP_CHECK(hipGetLastError());
+  {
+    KernelTimer kt(c, "gap:k_rs_hist_u32", (double)n * 4);
+    hipLaunchKernelGGL((k_rs_hist<u32, 2, false, DB2>), dim3(nblk2), dim3(RH_THREADS), 0, c.stream, (const u32 *)keys[1], n, low + b1,
+                       (1u << b2) - 1u, counts.get(), nblk2, none, (const uint2 *)tmap.get());
+    HIP_CHECK(hipGetLastError());
+  }
+  scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)(1 << DB2) * nblk2, nullptr);
+  {
+    KernelTimer kt(c, "gap:k_rs_scatter_u32_keys", (double)n * 6);
+    hipLaunchKernelGGL((k_rs_scatter<u32, false, 2, false, false, true, false, DB2>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream,
+                       (const u32 *)keys[1], (const u32 *)nullptr, keys[0], (u32 *)nullptr, n, low + b1, (1u << b2) - 1u, counts.get(),
+                       nblk2, none, 0u, (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)tmap.get(), (1u << low) - 1u);
+    HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_lean_bucket_starts, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk2,
+                     (const u32 *)tfirst.get(), b1, n_buckets, (u32)n, start);
+  HIP_CHECK(hipGetLastError());
+}
+
+void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start) {
+  if (n == 0 || n >= (1ull << 32) || b1 < 1 || b1 > 9 || b2 < 1 || b2 > 9 || low < 1 || low > 16)
+    fail(BWT_HIP_EINTERNAL, "gap sort: bad layout (n %zu, low %d, b1 %d, b2 %d)", n, low, b1, b2);
+  if (b1 > 8 && b2 > 8) gap_sort_lean_impl<9, 9>(c, keys, n, low, b1, b2, start);
+  else if (b2 > 8) gap_sort_lean_impl<8, 9>(c, keys, n, low, b1, b2, start);
+  else gap_sort_lean_impl<8, 8>(c, keys, n, low, b1, b2, start);
 }
 
 int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs) {
