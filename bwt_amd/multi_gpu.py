@@ -146,6 +146,9 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     import bwt_amd
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1:  # the one-rank rehearsal (BWT_BENCH_FORCE_DIST) is started without a launcher
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+            os.environ.setdefault(k, v)
     dist.init_process_group(backend="nccl", device_id=dev)
     n = args.n
     ctx = bwt_amd.Context(local_rank)

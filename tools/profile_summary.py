@@ -48,7 +48,7 @@ def main():
     # sectors, which the counter reports as they are (checked against the known count: one sector per LF step).
     pats = [("leaf:k_rs_scatter_u64_keys", "k_rs_scatter<unsigned long, false, 0, false, false,", 2),
             ("leaf:k_rs_scatter_u64_pairs", "k_rs_scatter<unsigned long, true, 0, false, true,", 2),
-            ("gap_chains", "k_chains<", 1)]
+            ("gap_chains", "bwtamd::k_chains(", 1)]
     kernels = {}
     for timer, pat, mult in pats:
         for k in fetch:
