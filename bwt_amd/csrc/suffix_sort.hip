@@ -1749,11 +1749,11 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
   // a text with long repeats goes straight to the plain passes and the refinement rounds
   const bool repeats = window_has_long_repeats(c, a, N);
-  // Windows the packed elements cannot index: lean elements up to 2^31 suffixes, wide ones beyond.  These routes
-  // settle every tie on the text itself, so they sort the leaf's own suffixes and no window slack.
+  // Large windows: lean elements up to 2^31 suffixes, wide ones beyond.  These routes settle every tie on the text
+  // itself, so they sort the leaf's own suffixes and no window slack.  (force_wide 3: never the lean route; windows
+  // the packed elements can index then take those elements' own bucket route, the lean route's predecessor.)
   const u64 NL = (u64)(b - a);
-  if (!repeats && (!kp.pbits || c.force_wide == 2) && c.force_wide != 1 && try_lean_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1)
-    return true;
+  if (!repeats && c.force_wide != 1 && c.force_wide != 3 && try_lean_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1) return true;
   if (!repeats && (!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
@@ -1768,7 +1768,9 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
       // element (16); every further pass reads the element for its histogram (8) and moves it (16).  The
       // bucket route stops after the second pass.
       Phase ph(c, "leaf_radix_sort", 0);
-      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, repeats ? nullptr : &bs, !repeats);
+      // the packed elements' own bucket route is what the lean route replaced: only where that one is switched off
+      const bool own_buckets = !repeats && c.force_wide == 3;
+      cur = leaf_sort_text_packed(c, el, N, begin_bit, tk, own_buckets ? &bs : nullptr, own_buckets);
       const int done = bs.pending ? 2 : passes;
       ph.add_work((double)N * (done <= 1 ? 10 : 11 + 17 + (done - 2) * 24));
     }

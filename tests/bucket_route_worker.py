@@ -84,6 +84,7 @@ def main():
     assert launches(ctx, "leaf:k_bucket_emit") > 0
     ctx.close()
     os.environ.pop("BWT_HIP_BUCKET_MIN_N")
+    os.environ.pop("BWT_HIP_FORCE_WIDE", None)
     ctx = bwt_amd.Context(0)
     ctx.set_timing(2)
     ctx.gen_text(n, 9, 4)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_bucket_route_on_small_texts():
-    env = dict(os.environ, BWT_HIP_BUCKET_MIN_N="1")
+    env = dict(os.environ, BWT_HIP_BUCKET_MIN_N="1", BWT_HIP_FORCE_WIDE="3")  # 3: not the lean route, which comes first otherwise
     r = subprocess.run([sys.executable, os.path.join(HERE, "bucket_route_worker.py")], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

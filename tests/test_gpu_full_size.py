@@ -60,7 +60,7 @@ def test_golden_large_pipeline(timed, rec):
     blk = ctx.pmbwt(rec["bwt_rec_threshold"], rec["ssa_n_samples"], rec["opts"].get("seg", 0))
     check_block(blk, blk.L, rec, 0, t["n"])
     if rec["name"].endswith("n1e8_1leaf"):
-        assert launches(ctx, "leaf:k_bucket_emit") == 1 and variants(ctx) == ["leaf:bucket_emit_items=4"]
+        assert launches(ctx, "leaf:k_bucket_emit") == 1 and variants(ctx) == ["leaf:bucket_emit_items=4,lean"]
     blk.free()
 
 
@@ -76,9 +76,9 @@ def test_golden_large_leaf(timed, rec):
     check_block(blk, blk.L, rec, 0, rec["b"] - rec["a"])
     # 5.6e8 suffixes are more than the packed 8-byte elements hold positions for (2^29): that window takes the lean
     # route (8-byte elements without the first pass's digit, 2^17 buckets)
-    want = {"leaf_s4_whole_5.3e8": ["leaf:bucket_emit_items=9"], "leaf_s4_whole_5.6e8": ["leaf:bucket_emit_items=5,lean"],
-            "leaf_s4_first_5e8_of_5.01e8": ["leaf:bucket_emit_items=8,slack"],
-            "leaf_s4_mid_3.6e8": ["leaf:bucket_emit_items=6,slack"]}[rec["name"]]
+    want = {"leaf_s4_whole_5.3e8": ["leaf:bucket_emit_items=9,lean"], "leaf_s4_whole_5.6e8": ["leaf:bucket_emit_items=5,lean"],
+            "leaf_s4_first_5e8_of_5.01e8": ["leaf:bucket_emit_items=8,lean"],
+            "leaf_s4_mid_3.6e8": ["leaf:bucket_emit_items=6,lean"]}[rec["name"]]
     assert launches(ctx, "leaf:k_bucket_emit") == len(want) and same_variants(variants(ctx), want), variants(ctx)
     blk.free()
 
@@ -149,12 +149,12 @@ def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves):
 def test_config2_n1e9_two_leaves(ctx):
     """Config 2 as bench.py --n 1000000000 --leaves 2 runs it: both leaves on the bucket route (8 elements per
     thread; the left one with window slack)."""
-    _full_size(ctx, 10 ** 9, 2, 12500000, ["leaf:bucket_emit_items=8", "leaf:bucket_emit_items=8,slack"], 4)
+    _full_size(ctx, 10 ** 9, 2, 12500000, ["leaf:bucket_emit_items=8,lean"], 4)
 
 
 def test_config3_n3_1e9_eight_leaves(ctx):
     """Config 3 on one GPU as bench.py runs it by default: 8 leaves of 3.875e8 suffixes, 7 merges."""
-    _full_size(ctx, 3100000000, 8, 19375000, ["leaf:bucket_emit_items=7", "leaf:bucket_emit_items=7,slack"], 4)
+    _full_size(ctx, 3100000000, 8, 19375000, ["leaf:bucket_emit_items=7,lean"], 4)
     ctx.trim()
 
 
