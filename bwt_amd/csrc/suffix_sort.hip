@@ -639,12 +639,15 @@ struct LeafEmit : EmitParams {
   }
 
   __device__ __forceinline__ bool note_fast(u64 r, u32 pos) const {
-    const u32 rel32 = pos - (u32)a;                // all positions are below 2^32
-    if (rel32 == 0) special[0] = (u32)r;           // s_rank
-    if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
-    if (m == 1) {
-      samp[0] = ((u64)pos << 32) | (u32)r;
-      return false;
+    const u32 rel32 = pos - (u32)a;  // all positions are below 2^32
+    if (rel32 == 0 || rel32 + 1 == (u32)m) {  // the leaf's first or last position: one rare branch for both
+      if (rel32 == 0) special[0] = (u32)r;           // s_rank
+      if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
+      if (m == 1) {
+        samp[0] = ((u64)pos << 32) | (u32)r;
+        return false;
+      }
+      return true;  // both ends are sampled; the exact expressions place them
     }
     // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
     // order, so the sample arrays come out sorted by position without a sort.  The two floor()
@@ -657,12 +660,11 @@ struct LeafEmit : EmitParams {
     // (0, ratio) the position is sampled whatever the roundings of the reference's two divisions do (they move
     // the quotient by far less than the margin) and its slot is the product's integer part; only a fractional part
     // within the margin of 0, of the ratio or of 1 needs the divisions themselves.
-    if (rel32 == 0) return true;
     const double q = (double)rel32 * samp_ratio;
     const double f = __builtin_amdgcn_fract(q);
     if (f > samp_ratio + 0x1p-16 && f < 1.0 - 0x1p-16) return false;
     if (f > 0x1p-16 && f < samp_ratio - 0x1p-16) {
-      samp[(i64)q] = ((u64)pos << 32) | (u32)r;
+      samp[(u32)q] = ((u64)pos << 32) | (u32)r;  // q < ns <= 2^32
       return false;
     }
     return true;
