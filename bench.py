@@ -127,7 +127,7 @@ def host_to_host(ctx, n, th, ns, seg, steps):
     dt = total / steps
     ok = bool(Lh.a[0] != 0 or n < 3) and int(sp[k - 1]) == n - 1
     out = {"value": round((n - 1) / dt / 1e6, 2), "unit": "Mbase/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-           "what": "T in page-locked host memory -> bwt_hip_pmbwt_host (upload overlapped with the first leaf) -> L and %d samples in page-locked host memory" % k,
+           "what": "T in page-locked host memory -> bwt_hip_pmbwt_host (text up and L down as two bits per symbol, upload overlapped with the first leaf) -> L and %d samples in page-locked host memory" % k,
            "sanity": ok}
     out.update({k_: round(v / steps, 3) for k_, v in parts.items()})
     for b in (Th, Lh, Sr, Sp):

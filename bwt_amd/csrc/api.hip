@@ -2,6 +2,7 @@
 // checks, exception -> status conversion, host<->device staging.
 #include <string.h>
 
+#include <chrono>
 #include <memory>
 #include <thread>
 
@@ -89,6 +90,8 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_WIDE_BBITS")) c.wide_bbits = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_ANY")) c.lean_any_order = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_GAP_LEAN")) c.gap_lean = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_HOST_PACK")) c.host_pack = atoi(v);
+  if (const char *v = getenv("BWT_HIP_XFER_CHUNK")) c.xfer_chunk = atoll(v);
   if (const char *v = getenv("BWT_HIP_DEFER_CHAINS")) c.defer_chains = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current
@@ -120,6 +123,10 @@ void bwt_hip_destroy(bwt_hip_ctx *ctx) {
   }
   for (auto &ch : c.chunks) (void)hipEventDestroy(ch.ev);
   for (auto e : c.chunk_events) (void)hipEventDestroy(e);
+  for (int k = 0; k < 3; k++) {
+    if (c.xfer_stage[k]) (void)hipHostFree(c.xfer_stage[k]);
+    if (c.xfer_ev[k]) (void)hipEventDestroy(c.xfer_ev[k]);
+  }
   if (c.copy_stream) {
     (void)hipStreamSynchronize(c.copy_stream);
     (void)hipStreamDestroy(c.copy_stream);
@@ -298,9 +305,9 @@ int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t th, int64_t ns, int64_t seg, bwt_hip
 }
 
 // max symbol, smallest non-zero symbol and number of zeros of a host text, on a few host threads
-static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 *n_zero) {
+static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int max_threads) {
   unsigned hw = std::thread::hardware_concurrency();
-  const int nt = n < (1 << 22) ? 1 : (hw > 16 ? 16 : (hw < 1 ? 1 : (int)hw));
+  const int nt = n < (1 << 22) ? 1 : (hw > (unsigned)max_threads ? max_threads : (hw < 1 ? 1 : (int)hw));
   std::vector<u32> mx((size_t)nt, 0), mn((size_t)nt, 255);
   std::vector<i64> nz((size_t)nt, 0);
   auto body = [&](int t) {
@@ -346,57 +353,131 @@ int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64
   c.T_owned = (u8 *)c.alloc((size_t)n + 64);
   HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
   c.sync();  // whatever used this memory before is done: the copy stream may write it
-  // first chunk: the leftmost leaf's window; then pieces of 256 MB
+  // Two ways up.  Packed (host_transfer.hip): a text of at most four consecutive symbol values, judged on a sample,
+  // goes up as two bits per symbol from a thread of its own, which also checks every symbol against the sample's
+  // range, so that the build starts without a pass over the text; a symbol outside that range makes wait_text
+  // throw TextMismatch before any kernel has read the chunk that holds it, and the call starts over the other way.
+  // Raw: the symbol statistics from a pass over the host text, first chunk = the leftmost leaf's window, then pieces
+  // of 256 MB, all enqueued here.
+  // BWT_HIP_XFER_TRACE=1: the host's view of this call's steps, in ms since its start, on stderr
+  const bool trace = getenv("BWT_HIP_XFER_TRACE") != nullptr && atoi(getenv("BWT_HIP_XFER_TRACE")) != 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (trace) fprintf(stderr, "[pmbwt_host] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+  };
+  int plo = 0, phi = 0;
+  const bool pack_size = (c.host_pack == 1 && n >= ((i64)1 << 24)) || (c.host_pack >= 2 && n >= 2);
+  if (pack_size) probe_symbol_range(T_host, n, &plo, &phi);
+  const bool try_packed = pack_size && plo >= 1 && plo <= 252 && phi - plo <= 3;
+  if (T_host[n - 1] != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", (int)T_host[n - 1]);
   i64 b0 = n;
   while (b0 > th && b0 >= 2) b0 = b0 / 2;
   i64 first = b0 + (b0 / 256 > 4096 ? b0 / 256 : 4096) + 4096;
   if (first > n) first = n;
+  std::thread uploader;
+  std::string upload_err;
   auto drain = [&]() {
+    c.xfer_abort.store(true);
+    if (uploader.joinable()) uploader.join();
+    c.xfer_abort.store(false);
+    c.xfer_mismatch.store(false);
     (void)hipStreamSynchronize(c.copy_stream);
     for (auto &ch : c.chunks) c.chunk_events.push_back(ch.ev);
     c.chunks.clear();
+    c.chunks_recorded = 0;
   };
-  try {
-    constexpr i64 PIECE = (i64)256 << 20;
-    for (i64 off = 0; off < n;) {
-      const i64 len = off == 0 ? first : (n - off < PIECE ? n - off : PIECE);
-      HIP_CHECK(hipMemcpyAsync(c.T_owned + off, T_host + off, (size_t)len, hipMemcpyHostToDevice, c.copy_stream));
-      hipEvent_t ev;
-      if (!c.chunk_events.empty()) {
-        ev = c.chunk_events.back();
-        c.chunk_events.pop_back();
-      } else {
-        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      }
-      HIP_CHECK(hipEventRecord(ev, c.copy_stream));
-      off += len;
-      c.chunks.push_back({(u64)off, ev, false});
+  auto chunk_event = [&]() {
+    hipEvent_t ev;
+    if (!c.chunk_events.empty()) {
+      ev = c.chunk_events.back();
+      c.chunk_events.pop_back();
+    } else {
+      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    // the text's statistics (which symbols occur decides the layout of every sort key and rank block) come from
-    // the host copy while the first chunk is on its way
-    int max_sym = 0, min_sym = 0;
-    i64 n_zero = 0;
-    host_text_stats(T_host, n, &max_sym, &min_sym, &n_zero);
-    if (T_host[n - 1] != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", (int)T_host[n - 1]);
-    if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
-    c.T = c.T_owned;
-    c.n = n;
-    c.max_sym = max_sym;
-    c.min_sym = min_sym;
-    int bits = 1;
-    while ((max_sym >> bits) != 0) bits++;
-    c.sym_bits = bits;
-    std::unique_ptr<Block> blk(do_rec(c, 0, n, th, ns, seg));
-    c.wait_text((u64)n);
-    if (L_host) HIP_CHECK(hipMemcpyAsync(L_host, blk->L.get(), (size_t)n, hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    drain();
-    *out = publish(c, blk.release());
-  } catch (...) {
-    drain();
-    (void)hipStreamSynchronize(c.stream);
-    drop_text(c);
-    throw;
+    return ev;
+  };
+  for (int attempt = 0;; attempt++) {
+    const bool packed = try_packed && attempt == 0;
+    try {
+      DBuf<u8> dpacked;
+      c.chunks_recorded = 0;
+      int max_sym = 0, min_sym = 0;
+      if (packed) {
+        prepare_packed_upload(c);
+        dpacked = DBuf<u8>(c, (size_t)(n / 4 + 64));
+        c.sync();
+        const i64 piece = c.xfer_chunk;
+        for (i64 off = 0; off < n;) {
+          const i64 len = n - off < piece ? n - off : piece;
+          off += len;
+          c.chunks.push_back({(u64)off, chunk_event(), false});
+        }
+        uploader = std::thread(upload_text_packed, std::ref(c), T_host, n, (u32)plo, (u32)(phi - plo), dpacked.get(), &upload_err);
+        // the sample saw plo and phi; the uploader lets nothing else through: these are the text's statistics
+        min_sym = plo;
+        max_sym = phi;
+        mark("uploader started (packed)");
+      } else {
+        constexpr i64 PIECE = (i64)256 << 20;
+        for (i64 off = 0; off < n;) {
+          const i64 len = off == 0 ? first : (n - off < PIECE ? n - off : PIECE);
+          HIP_CHECK(hipMemcpyAsync(c.T_owned + off, T_host + off, (size_t)len, hipMemcpyHostToDevice, c.copy_stream));
+          hipEvent_t ev = chunk_event();
+          HIP_CHECK(hipEventRecord(ev, c.copy_stream));
+          off += len;
+          c.chunks.push_back({(u64)off, ev, false});
+        }
+        c.chunks_recorded = c.chunks.size();
+        mark("upload enqueued (raw)");
+        // the text's statistics (which symbols occur decides the layout of every sort key and rank block) come from
+        // the host copy while the first chunk is on its way
+        i64 n_zero = 0;
+        host_text_stats(T_host, n, &max_sym, &min_sym, &n_zero, 16);
+        mark("text statistics done");
+        if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
+      }
+      c.T = c.T_owned;
+      c.n = n;
+      c.max_sym = max_sym;
+      c.min_sym = min_sym;
+      int bits = 1;
+      while ((max_sym >> bits) != 0) bits++;
+      c.sym_bits = bits;
+      std::unique_ptr<Block> blk(do_rec(c, 0, n, th, ns, seg));
+      mark("build enqueued");
+      c.wait_text((u64)n);
+      if (uploader.joinable()) uploader.join();
+      if (trace) {
+        c.sync();
+        mark("build finished on the device");
+      }
+      if (!upload_err.empty()) fail(BWT_HIP_EINTERNAL, "upload of the text: %s", upload_err.c_str());
+      if (L_host) {
+        if (pack_size && min_sym >= 1 && max_sym - min_sym <= 3)
+          download_packed(c, blk->L.get(), n, (u32)(min_sym > 252 ? 252 : min_sym), blk->s_rank, L_host);
+        else
+          HIP_CHECK(hipMemcpyAsync(L_host, blk->L.get(), (size_t)n, hipMemcpyDeviceToHost, c.stream));
+      }
+      c.sync();
+      mark("L in host memory");
+      drain();
+      *out = publish(c, blk.release());
+      break;
+    } catch (const TextMismatch &) {
+      drain();
+      (void)hipStreamSynchronize(c.stream);
+      c.T = nullptr;
+      if (!packed) {  // only a packed upload raises it
+        drop_text(c);
+        fail(BWT_HIP_EINTERNAL, "text mismatch outside a packed upload");
+      }
+      mark("a symbol outside the sampled range: starting over, unpacked");
+    } catch (...) {
+      drain();
+      (void)hipStreamSynchronize(c.stream);
+      drop_text(c);
+      throw;
+    }
   }
   API_END
 }

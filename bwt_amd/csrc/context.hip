@@ -119,8 +119,14 @@ void Ctx::trim() {
 void Ctx::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
 void Ctx::wait_text(u64 upto) {
-  for (auto &ch : chunks) {
+  for (size_t i = 0; i < chunks.size(); i++) {
+    TextChunk &ch = chunks[i];
     if (!ch.waited) {
+      {
+        std::unique_lock<std::mutex> lk(chunk_mu);
+        chunk_cv.wait(lk, [&] { return chunks_recorded > i; });
+      }
+      if (xfer_mismatch.load()) throw TextMismatch();
       HIP_CHECK(hipStreamWaitEvent(stream, ch.ev, 0));
       ch.waited = true;
     }

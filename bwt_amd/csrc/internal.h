@@ -6,7 +6,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -55,6 +58,10 @@ struct PhaseTimer {
   long launches = 0;
 };
 
+// Thrown by Ctx::wait_text when the thread that uploads a packed text has met a symbol outside the range the build
+// was started with; nothing has read that part of the text yet.
+struct TextMismatch {};
+
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -80,6 +87,17 @@ struct Ctx {
   std::vector<TextChunk> chunks;
   std::vector<hipEvent_t> chunk_events;  // spare events of finished uploads (made without timing: not for the timers' pool)
   void wait_text(u64 upto);
+  // A packed upload (host_transfer.hip) records the chunks' events from a thread of its own: wait_text first waits,
+  // on the host, until the chunk's event has been recorded at all.
+  std::mutex chunk_mu;
+  std::condition_variable chunk_cv;
+  size_t chunks_recorded = 0;
+  std::atomic<bool> xfer_abort{false};
+  std::atomic<bool> xfer_mismatch{false};  // the uploader met a symbol outside the range the build was started with
+  unsigned char *xfer_stage[3] = {nullptr, nullptr, nullptr};  // page-locked staging buffers, made at first use
+  hipEvent_t xfer_ev[3] = {nullptr, nullptr, nullptr};
+  i64 xfer_chunk = (i64)256 << 20;  // symbols per chunk of a packed transfer (BWT_HIP_XFER_CHUNK; tests make it small)
+  int host_pack = 1;  // texts of up to four consecutive symbol values cross the link as two bits per symbol: 0 never, 1 from 2^24 symbols, 2 always
 
   // caching allocator (sizes rounded up; freed blocks are kept for reuse)
   std::multimap<size_t, void *> free_blocks;
@@ -381,6 +399,12 @@ void resample_part(Ctx &c, const ResamplePart &R);
 // api.hip: bwt_rec (leaf iff b-a <= th, else split at (a+b)/2 and merge); the calling thread's error message
 Block *build_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg);
 void set_last_error(const char *msg);
+
+// host_transfer.hip
+void probe_symbol_range(const u8 *T, i64 n, int *lo, int *hi);
+void prepare_packed_upload(Ctx &c);
+void upload_text_packed(Ctx &c, const u8 *T_host, i64 n, u32 min_sym, u32 span, u8 *dpacked, std::string *err);
+void download_packed(Ctx &c, const u8 *L_dev, i64 n, u32 min_sym, i64 foreign, u8 *L_host);
 
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
 void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);

@@ -128,6 +128,80 @@ def test_pmbwt_host_overlapped_upload(ctx, n, sigma, th, ns):
         assert (Oracle.pmbwt(T, o).L == Lh).all()
 
 
+@pytest.fixture()
+def pack_ctx(monkeypatch):
+    """A context of its own that packs every eligible text whatever its size, in chunks of 1M symbols, so that
+    small texts exercise many chunks, the reuse of the staging buffers and ragged tails."""
+    import bwt_amd
+    monkeypatch.setenv("BWT_HIP_HOST_PACK", "2")
+    monkeypatch.setenv("BWT_HIP_XFER_CHUNK", str(1 << 20))
+    c = bwt_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _host_equals_device_path(c, ref_ctx, T, th, ns):
+    n = len(T)
+    Lh = np.full(n, 0xEE, dtype=np.uint8)
+    blk = c.pmbwt_host(T, th, ns, 0, Lh)
+    ref_ctx.set_text(T)
+    ref = ref_ctx.pmbwt(th, ns)
+    assert (ref.L == Lh).all() and (blk.L == Lh).all()
+    assert (ref.s_rank, ref.e_rank) == (blk.s_rank, blk.e_rank)
+    for x, y in zip(blk.samples(), ref.samples()):
+        assert (x == y).all()
+    assert (c.get_text() == T).all()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 17, 64, 4099, 1 << 20, (1 << 20) + 1, (1 << 20) + 2, 7777777])
+def test_pmbwt_host_packed_transfer_sizes(ctx, pack_ctx, n):
+    """Texts of four symbol values cross the link as two bits per symbol (host_transfer.hip): same block and same L
+    as the device-resident path, at lengths around the packing groups' and the chunks' edges."""
+    T = make_text({"kind": "splitmix", "n": n, "seed": 5 + n, "sigma": 4})
+    _host_equals_device_path(pack_ctx, ctx, T, n if n < 5 else n // 3, max(2, min(n // 3, 5000)))
+
+
+@pytest.mark.parametrize("shift,sigma,n", [(96, 4, 3333333), (0, 3, 3333333), (200, 2, 2222222), (251, 4, 3333333), (0, 1, 100001)])
+def test_pmbwt_host_packed_transfer_alphabets(ctx, pack_ctx, shift, sigma, n):
+    """Any four consecutive symbol values pack (a..d, 252..255), fewer than four too."""
+    T = make_text({"kind": "splitmix", "n": n, "seed": 99, "sigma": sigma})
+    T[:-1] += shift
+    _host_equals_device_path(pack_ctx, ctx, T, n // 2, 4000)
+
+
+def test_pmbwt_host_packed_transfer_foreign_symbols(ctx, pack_ctx):
+    """The sample that decides on packing, and that the build's symbol statistics are taken from, can miss rare
+    symbols: the uploader meets them before the build reads their chunk, and the call starts over unpacked."""
+    n = 5000011
+    T = make_text({"kind": "splitmix", "n": n, "seed": 3, "sigma": 4})
+    T[:-1] += 64
+    for at, v in ((1234567, 64 + 9), (1234568, 7), (4999999, 255), (n - 2, 70)):
+        T[at] = v
+    _host_equals_device_path(pack_ctx, ctx, T, n // 2, 4000)
+    # four values in all, but not the ones the sample saw
+    T = make_text({"kind": "splitmix", "n": n, "seed": 4, "sigma": 3})
+    T[:-1] += 1  # 2..4 ... and one 1 the sample does not see
+    T[2500001] = 1
+    _host_equals_device_path(pack_ctx, ctx, T, n // 2, 4000)
+
+
+def test_pmbwt_host_packed_rejects_bad_texts(pack_ctx):
+    import bwt_amd
+    n = 3000000
+    T = make_text({"kind": "splitmix", "n": n, "seed": 3, "sigma": 4})
+    bad = T.copy()
+    bad[1500000] = 0
+    with pytest.raises(bwt_amd.BwtHipError):
+        pack_ctx.pmbwt_host(bad, n, 100)
+    bad = T.copy()
+    bad[-1] = 2
+    with pytest.raises(bwt_amd.BwtHipError):
+        pack_ctx.pmbwt_host(bad, n, 100)
+    Lh = np.zeros(n, dtype=np.uint8)
+    blk = pack_ctx.pmbwt_host(T, n, 100, 0, Lh)
+    assert blk.ibwt_mismatches() == 0 and (blk.L == Lh).all()
+
+
 def test_pmbwt_host_rejects_bad_texts(ctx):
     import bwt_amd
     for bad in (b"abc", b"a\0b\0", b"\0\0"):
