@@ -643,11 +643,13 @@ struct LeafEmit : EmitParams {
     if (rel32 == 0 || rel32 + 1 == (u32)m) {  // the leaf's first or last position: one rare branch for both
       if (rel32 == 0) special[0] = (u32)r;           // s_rank
       if (rel32 + 1 == (u32)m) special[1] = (u32)r;  // e_rank
-      if (m == 1) {
-        samp[0] = ((u64)pos << 32) | (u32)r;
-        return false;
-      }
-      return true;  // both ends are sampled; the exact expressions place them
+      // Both ends are always sampled (include/bwt.h:296-299): the first in slot 0, the last in slot ns - 1.  The
+      // reference's floor expressions say the same while (b-a)(ns-1) < 2^53; beyond that the product's
+      // conversion to double can round the last position's quotient below ns - 1 and lose that sample (an
+      // assertion failure there, :347), so the ends are placed here and not by those expressions.
+      if (rel32 == 0) samp[0] = ((u64)pos << 32) | (u32)r;
+      if (rel32 + 1 == (u32)m && m > 1) samp[ns - 1] = ((u64)pos << 32) | (u32)r;
+      return false;
     }
     // A sampled position i lands in slot y = floor((i-a)(ns-1)/(b-a-1)): slots are in position
     // order, so the sample arrays come out sorted by position without a sort.  The two floor()

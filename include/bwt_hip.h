@@ -99,6 +99,10 @@ int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t bwt_rec_threshold, int64_t ssa_n_sam
    bwt_hip_pmbwt + bwt_hip_block_get_L, with the upload overlapped: the text goes up in chunks on a stream
    of its own, the first leaf's sort starts when its window has arrived, and the text's statistics are taken from
    the host copy meanwhile.  Page-locked buffers (bwt_hip_host_alloc) make both copies run at the link's rate.
+   A text of 2^24 symbols or more whose symbols span at most four consecutive values (DNA) crosses the link as two
+   bits per symbol in both directions, through page-locked staging the context keeps (192 MB): T and L may then be
+   pageable memory at no cost, and host threads of this call (up to 16) do the packing, which also validates the
+   text, so no separate pass over it precedes the build.
    The context holds the text afterwards, as after bwt_hip_set_text. */
 int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64_t bwt_rec_threshold,
                        int64_t ssa_n_samples, int64_t build_gap_segment_sz, uint8_t *L_host, bwt_hip_block **out);

@@ -185,6 +185,25 @@ def test_n3_1e9_one_leaf_wide_route(ctx):
     ctx.trim()
 
 
+def test_n3_1e9_both_ends_sampled_beyond_2_53(ctx):
+    """(b-a)(ns-1) beyond 2^53, where the product of the reference's sample test (include/bwt.h:339-340) no longer
+    converts to double exactly: with the CLI's default ssa_n_samples at n = 3.1e9 the last position's quotient rounds
+    below ns-1 there.  Both ends of every leaf are sampled all the same (:296-299), ns samples in all, in position
+    order, each with L[rank] = T[pos-1]."""
+    n = 3100000000
+    ctx.gen_text(n, 42, 4)
+    for ns in (15499999, 38750000, 2 ** 25 + 1):
+        blk = ctx.pmbwt(n // 2, ns)
+        r, p = blk.samples()
+        assert len(p) == ns and p[0] == 0 and p[-1] == n - 1 and (np.diff(p) > 0).all()
+        if ns == 15499999:
+            L, T = blk.L, ctx.get_text()
+            assert (L[r] == T[p - 1]).all()
+            del L, T
+        blk.free()
+    ctx.trim()
+
+
 def test_config4_repetitive_4_6e8(ctx):
     """Config 4 at full size: 100 copies of a 4.6e6-symbol genome with 0.1 % substitutions (LCPs of thousands),
     two leaves and one merge.  The reference's comparison sort does not finish this text in reasonable time, so:
