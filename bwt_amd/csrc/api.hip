@@ -350,8 +350,15 @@ int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64
   HIP_CHECK(hipSetDevice(c.device));
   drop_text(c);
   if (!c.copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  if (T_host[n - 1] != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", (int)T_host[n - 1]);
   c.T_owned = (u8 *)c.alloc((size_t)n + 64);
-  HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
+  // The terminator is in place before anything else: the leaf that starts at 0 reads T[n-1] as the symbol before
+  // position 0, long before the last chunk of the text arrives (which writes the same 0 again).
+  HIP_CHECK(hipMemsetAsync(c.T_owned + n - 1, 0, 65, c.stream));
+  // BWT_HIP_POISON_TEXT=1 (tests): the text's memory starts as a byte no test text holds, so that a kernel which
+  // reads a chunk before it has arrived shows in the result instead of finding a previous call's copy of the text
+  if (n > 1 && getenv("BWT_HIP_POISON_TEXT") && atoi(getenv("BWT_HIP_POISON_TEXT")) != 0)
+    HIP_CHECK(hipMemsetAsync(c.T_owned, 0xA5, (size_t)n - 1, c.stream));
   c.sync();  // whatever used this memory before is done: the copy stream may write it
   // Two ways up.  Packed (host_transfer.hip): a text of at most four consecutive symbol values, judged on a sample,
   // goes up as two bits per symbol from a thread of its own, which also checks every symbol against the sample's
@@ -369,7 +376,6 @@ int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64
   const bool pack_size = (c.host_pack == 1 && n >= ((i64)1 << 24)) || (c.host_pack >= 2 && n >= 2);
   if (pack_size) probe_symbol_range(T_host, n, &plo, &phi);
   const bool try_packed = pack_size && plo >= 1 && plo <= 252 && phi - plo <= 3;
-  if (T_host[n - 1] != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", (int)T_host[n - 1]);
   i64 b0 = n;
   while (b0 > th && b0 >= 2) b0 = b0 / 2;
   i64 first = b0 + (b0 / 256 > 4096 ? b0 / 256 : 4096) + 4096;

@@ -108,7 +108,7 @@ static void unpack_chunk(const u8 *src, i64 count, u8 *dst, u32 min_sym, int nt)
 static void ensure_staging(Ctx &c) {
   if (c.xfer_stage[0]) return;
   for (int s = 0; s < XF_SLOTS; s++) {
-    HIP_CHECK(hipHostMalloc((void **)&c.xfer_stage[s], (size_t)(XF_CHUNK / 4), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&c.xfer_stage[s], (size_t)(c.xfer_chunk / 4), hipHostMallocDefault));
     HIP_CHECK(hipEventCreateWithFlags(&c.xfer_ev[s], hipEventDisableTiming));
   }
 }
@@ -216,7 +216,7 @@ void prepare_packed_upload(Ctx &c) {
   if (c.xfer_chunk > XF_CHUNK) c.xfer_chunk = XF_CHUNK;
   if (c.xfer_chunk < 4096) c.xfer_chunk = 4096;
   c.xfer_chunk &= ~(i64)63;
-  ensure_staging(c);
+  ensure_staging(c);  // sized by xfer_chunk, which does not change once the buffers exist (read when the context is made)
 }
 
 }  // namespace bwtamd

@@ -135,6 +135,7 @@ def pack_ctx(monkeypatch):
     import bwt_amd
     monkeypatch.setenv("BWT_HIP_HOST_PACK", "2")
     monkeypatch.setenv("BWT_HIP_XFER_CHUNK", str(1 << 20))
+    monkeypatch.setenv("BWT_HIP_POISON_TEXT", "1")  # a read ahead of the upload must show
     c = bwt_amd.Context(0)
     yield c
     c.close()
