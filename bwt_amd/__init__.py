@@ -72,6 +72,9 @@ def lib():
         "bwt_hip_dist_bounds": [i64, i32, _i64p],
         "bwt_hip_dist_chains": [vp, vp, i64, i64, i64, vp],
         "bwt_hip_dist_partition": [vp, vp, i64, i64, i32, vp, _i64p],
+        "bwt_hip_dist_wire_packable": [vp, C.POINTER(i32)],
+        "bwt_hip_dist_wire_pack": [vp, vp, i64, vp],
+        "bwt_hip_dist_wire_unpack": [vp, vp, i64, vp],
         "bwt_hip_dist_merge_slice": [vp, vp, i64, vp, i64, vp, vp, vp],
         "bwt_hip_dist_merge_slice_noalloc": [vp, vp, i64, vp, i64, vp, vp, vp],
         "bwt_hip_dist_resample": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, vp, vp, _i64p],
@@ -346,6 +349,17 @@ class Context:
         counts = np.zeros(parts, dtype=np.int64)
         _chk(lib().bwt_hip_dist_partition(self._h, C.c_void_p(g_ptr), count, m, parts, C.c_void_p(out_ptr), _p(counts, _i64p)))
         return counts
+
+    def dist_wire_packable(self):
+        ok = C.c_int(0)
+        _chk(lib().bwt_hip_dist_wire_packable(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def dist_wire_pack(self, src_ptr, count, packed_ptr):
+        _chk(lib().bwt_hip_dist_wire_pack(self._h, C.c_void_p(src_ptr), count, C.c_void_p(packed_ptr)))
+
+    def dist_wire_unpack(self, packed_ptr, count, dst_ptr):
+        _chk(lib().bwt_hip_dist_wire_unpack(self._h, C.c_void_p(packed_ptr), count, C.c_void_p(dst_ptr)))
 
     def dist_merge_slice(self, lL_ptr, mL, rL_ptr, rn, g_ptr, out_ptr, S_ptr):
         _chk(lib().bwt_hip_dist_merge_slice(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),

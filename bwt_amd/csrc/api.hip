@@ -830,6 +830,35 @@ int bwt_hip_dist_partition(bwt_hip_ctx *ctx, const uint32_t *g_dev, int64_t coun
   API_END
 }
 
+int bwt_hip_dist_wire_packable(bwt_hip_ctx *ctx, int *packable) {
+  API_BEGIN
+  need(ctx && packable, "ctx, packable");
+  *packable = wire_packable(ctx->c) ? 1 : 0;
+  API_END
+}
+
+int bwt_hip_dist_wire_pack(bwt_hip_ctx *ctx, const uint8_t *src_dev, int64_t count, uint8_t *packed_dev) {
+  API_BEGIN
+  need(ctx && count >= 0 && (count == 0 || (src_dev && packed_dev)), "ctx, count >= 0, src_dev, packed_dev");
+  Ctx &c = ctx->c;
+  need(wire_packable(c), "a text whose symbols span at most four consecutive values");
+  HIP_CHECK(hipSetDevice(c.device));
+  wire_pack2(c, src_dev, (u64)count, packed_dev);
+  c.sync();
+  API_END
+}
+
+int bwt_hip_dist_wire_unpack(bwt_hip_ctx *ctx, const uint8_t *packed_dev, int64_t count, uint8_t *dst_dev) {
+  API_BEGIN
+  need(ctx && count >= 0 && (count == 0 || (packed_dev && dst_dev)), "ctx, count >= 0, packed_dev, dst_dev");
+  Ctx &c = ctx->c;
+  need(wire_packable(c), "a text whose symbols span at most four consecutive values");
+  HIP_CHECK(hipSetDevice(c.device));
+  wire_unpack2(c, packed_dev, (u64)count, dst_dev);
+  c.sync();
+  API_END
+}
+
 int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
                              uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev) {
   API_BEGIN

@@ -104,6 +104,78 @@ void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, 
   }
 }
 
+// ----------------------------------------------------------------------------
+// Symbols on the wire between GPUs.  When the text's symbols span at most four consecutive values (DNA), a
+// stretch of L travels as two bits per symbol: code = (symbol - min_sym) & 3, four symbols per byte, the
+// first in the lowest bits.  Source and destination stretches start at arbitrary symbol offsets (slices of a
+// block are cut by rank), so both kernels work from a byte pointer of any alignment; the packed stream itself
+// always starts at a byte.  A symbol outside the range (the terminator that the block starting at text position
+// 0 holds at s_rank) packs as garbage and is put back by the receiver.
+// ----------------------------------------------------------------------------
+__global__ void k_wire_pack2(const u8 *__restrict__ src, u64 count, u8 *__restrict__ packed, u32 min_sym) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 i0 = t * 16;
+  if (i0 >= count) return;
+  if (i0 + 16 <= count) {
+    u64 v[2];
+    __builtin_memcpy(v, src + i0, 16);  // any alignment
+    u32 w = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const u32 in = (u32)(v[q >> 1] >> (32 * (q & 1)));
+      // (symbol - min_sym) mod 4 per byte; the 4 added to every byte keeps a borrow from crossing into its neighbour
+      const u32 x = ((in & 0x03030303u) | 0x04040404u) - (min_sym & 3u) * 0x01010101u;
+      w |= ((x & 3u) | (((x >> 8) & 3u) << 2) | (((x >> 16) & 3u) << 4) | (((x >> 24) & 3u) << 6)) << (8 * q);
+    }
+    __builtin_memcpy(packed + t * 4, &w, 4);
+  } else {
+    for (u64 i = i0; i < count; i += 4) {
+      u32 b = 0;
+      for (u64 j = i; j < i + 4 && j < count; j++) b |= ((u32)(src[j] - min_sym) & 3u) << (2 * (j - i));
+      packed[i >> 2] = (u8)b;
+    }
+  }
+}
+
+// dst[i] = min_sym + code i of the packed stream, i in [0, count).  A thread owns one 16-byte aligned group of
+// destination bytes; groups that the stretch covers only partly (its two ends) are written byte by byte.
+__global__ void k_wire_unpack2(const u8 *__restrict__ packed, u8 *__restrict__ dst, u64 count, u32 min_sym) {
+  const u64 lead = (u64)(reinterpret_cast<uintptr_t>(dst) & 15);  // bytes between the aligned group start and dst
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t * 16 >= lead + count) return;
+  const i64 s0 = (i64)(t * 16) - (i64)lead;  // stream index of the group's first byte
+  if (s0 >= 0 && (u64)s0 + 16 <= count) {
+    u64 w;
+    __builtin_memcpy(&w, packed + (s0 >> 2), 8);  // 32 + 6 bits are needed; the caller pads the stream by 8 bytes
+    const u32 bits = (u32)(w >> (2 * (s0 & 3)));
+    u32 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const u32 b = (bits >> (8 * q)) & 255u;
+      o[q] = ((b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | ((b >> 6) << 24)) + min_sym * 0x01010101u;
+    }
+    *reinterpret_cast<uint4 *>(dst + s0) = make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+    const i64 lo = s0 < 0 ? 0 : s0, hi = s0 + 16 < (i64)count ? s0 + 16 : (i64)count;
+    for (i64 i = lo; i < hi; i++) dst[i] = (u8)(min_sym + ((packed[i >> 2] >> (2 * (i & 3))) & 3u));
+  }
+}
+
+bool wire_packable(const Ctx &c) { return c.min_sym >= 1 && c.max_sym >= c.min_sym && c.max_sym - c.min_sym <= 3; }
+
+void wire_pack2(Ctx &c, const u8 *src, u64 count, u8 *packed) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_wire_pack2, dim3(ceil_div((count + 15) / 16, 256)), dim3(256), 0, c.stream, src, count, packed, (u32)c.min_sym);
+  HIP_CHECK(hipGetLastError());
+}
+
+void wire_unpack2(Ctx &c, const u8 *packed, u64 count, u8 *dst) {
+  if (count == 0) return;
+  const u64 lead = (u64)(reinterpret_cast<uintptr_t>(dst) & 15);
+  hipLaunchKernelGGL(k_wire_unpack2, dim3(ceil_div((lead + count + 15) / 16, 256)), dim3(256), 0, c.stream, packed, dst, count, (u32)c.min_sym);
+  HIP_CHECK(hipGetLastError());
+}
+
 void partition_bounds(u64 m, u32 parts, i64 *lo_out) {
   const u64 scale = (((u64)parts) << 32) / (m + 1);
   for (u32 k = 0; k < parts; k++) lo_out[k] = (i64)part_lower_bound(k, scale);

@@ -205,16 +205,34 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   lb->s_rank = s_rank_l - a;
   lb->e_rank = e_rank_l - a;
   lb->L = DBuf<u8>(c, (size_t)m);
+  const bool packed_wire = wire_packable(c);  // the same on every member: they hold the same text
   {
+    // two bits per symbol on the wire where the alphabet allows it: a quarter of the bytes, which at the top
+    // of the tree are the largest transfer of the build (every member receives the whole left block)
     std::vector<bwt_hip_p2p> ops;
+    std::vector<size_t> in_at((size_t)q + 1, 0);
+    for (int j = 0; j < q; j++)
+      in_at[(size_t)j + 1] = in_at[(size_t)j] + ((packed_wire && j != k) ? ((wire_bytes((u64)M(j, 5)) + WIRE_PAD + 15) & ~(size_t)15) : 0);
+    DBuf<u8> in_pk(c, in_at[(size_t)q] + 16), out_pk(c, (packed_wire && k < q ? wire_bytes((u64)M(k, 5)) : 0) + 16);
     if (k < q) {
       HIP_CHECK(hipMemcpyAsync(lb->L.get() + loff[(size_t)k], blk->L.get(), (size_t)M(k, 5), hipMemcpyDeviceToDevice, c.stream));
+      if (packed_wire) wire_pack2(c, blk->L.get(), (u64)M(k, 5), out_pk.get());
       for (int j = 0; j < G; j++)
-        if (j != k) ops.push_back({g.first + j, 1, blk->L.get(), M(k, 5)});
+        if (j != k) ops.push_back({g.first + j, 1, packed_wire ? out_pk.get() : blk->L.get(), packed_wire ? (i64)wire_bytes((u64)M(k, 5)) : M(k, 5)});
     }
     for (int j = 0; j < q; j++)
-      if (j != k) ops.push_back({g.first + j, 0, lb->L.get() + loff[(size_t)j], M(j, 5)});
+      if (j != k) {
+        if (packed_wire) ops.push_back({g.first + j, 0, in_pk.get() + in_at[(size_t)j], (i64)wire_bytes((u64)M(j, 5))});
+        else ops.push_back({g.first + j, 0, lb->L.get() + loff[(size_t)j], M(j, 5)});
+      }
     g.exchange(ops);
+    if (packed_wire) {
+      for (int j = 0; j < q; j++)
+        if (j != k) wire_unpack2(c, in_pk.get() + in_at[(size_t)j], (u64)M(j, 5), lb->L.get() + loff[(size_t)j]);
+      // the block that starts at text position 0 holds the terminator at s_rank, which has no two-bit code
+      if (a == 0) HIP_CHECK(hipMemsetAsync(lb->L.get() + (s_rank_l - a), 0, 1, c.stream));
+      c.sync();  // the packed buffers die here
+    }
   }
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (cpos - 1), 1, hipMemcpyDeviceToHost, c.stream));
   c.sync();
@@ -253,7 +271,34 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
     send_b[(size_t)d] = k >= q ? overlap(roff[(size_t)(k - q)], roff[(size_t)(k - q + 1)], rb[(size_t)d], rb[(size_t)d + 1]) : 0;
     recv_b[(size_t)d] = d >= q ? overlap(roff[(size_t)(d - q)], roff[(size_t)(d - q + 1)], rb[(size_t)k], rb[(size_t)k + 1]) : 0;
   }
-  g.all_to_all(k >= q ? blk->L.get() : (const u8 *)rL.get(), send_b, rL.get(), recv_b);
+  if (!packed_wire) {
+    g.all_to_all(k >= q ? blk->L.get() : (const u8 *)rL.get(), send_b, rL.get(), recv_b);
+  } else {
+    // the same pieces as two bits per symbol: a holder's pieces follow each other in its slice, a part's in rL
+    std::vector<size_t> s_at((size_t)G + 1, 0), r_at((size_t)G + 1, 0), s_sym((size_t)G + 1, 0), r_sym((size_t)G + 1, 0);
+    for (int d = 0; d < G; d++) {
+      s_sym[(size_t)d + 1] = s_sym[(size_t)d] + (size_t)send_b[(size_t)d];
+      r_sym[(size_t)d + 1] = r_sym[(size_t)d] + (size_t)recv_b[(size_t)d];
+      s_at[(size_t)d + 1] = s_at[(size_t)d] + (d != k ? ((wire_bytes((u64)send_b[(size_t)d]) + 15) & ~(size_t)15) : 0);
+      r_at[(size_t)d + 1] = r_at[(size_t)d] + (d != k ? ((wire_bytes((u64)recv_b[(size_t)d]) + WIRE_PAD + 15) & ~(size_t)15) : 0);
+    }
+    DBuf<u8> s_pk(c, s_at[(size_t)G] + 16), r_pk(c, r_at[(size_t)G] + 16);
+    std::vector<bwt_hip_p2p> ops;
+    for (int d = 0; d < G; d++)
+      if (d != k && send_b[(size_t)d] > 0) {
+        wire_pack2(c, blk->L.get() + s_sym[(size_t)d], (u64)send_b[(size_t)d], s_pk.get() + s_at[(size_t)d]);
+        ops.push_back({g.first + d, 1, s_pk.get() + s_at[(size_t)d], (i64)wire_bytes((u64)send_b[(size_t)d])});
+      }
+    for (int d = 0; d < G; d++)
+      if (d != k && recv_b[(size_t)d] > 0) ops.push_back({g.first + d, 0, r_pk.get() + r_at[(size_t)d], (i64)wire_bytes((u64)recv_b[(size_t)d])});
+    if (send_b[(size_t)k] != recv_b[(size_t)k]) fail(BWT_HIP_EINTERNAL, "right symbols: own piece %ld != %ld", (long)send_b[(size_t)k], (long)recv_b[(size_t)k]);
+    if (send_b[(size_t)k] > 0)
+      HIP_CHECK(hipMemcpyAsync(rL.get() + r_sym[(size_t)k], blk->L.get() + s_sym[(size_t)k], (size_t)send_b[(size_t)k], hipMemcpyDeviceToDevice, c.stream));
+    g.exchange(ops);
+    for (int d = 0; d < G; d++)
+      if (d != k && recv_b[(size_t)d] > 0) wire_unpack2(c, r_pk.get() + r_at[(size_t)d], (u64)recv_b[(size_t)d], rL.get() + r_sym[(size_t)d]);
+    c.sync();  // the packed buffers die here
+  }
 
   // 4. this part's slice of the merged block
   std::vector<i64> lo((size_t)G + 1);

@@ -381,6 +381,14 @@ Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
 // dist.hip: pieces of a merge spread over several GPUs
 void partition_bounds(u64 m, u32 parts, i64 *lo_out);
 void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host);
+// Symbols between GPUs as two bits each (texts whose symbols span at most four consecutive values): `count`
+// symbols at src (any alignment) -> wire_bytes(count) bytes at packed, and back to dst (any alignment).  The
+// unpacking kernel reads up to WIRE_PAD bytes past the packed stream: buffers that receive one are that much longer.
+bool wire_packable(const Ctx &c);
+static inline size_t wire_bytes(u64 count) { return (size_t)((count + 3) / 4); }
+constexpr size_t WIRE_PAD = 8;
+void wire_pack2(Ctx &c, const u8 *src, u64 count, u8 *packed);
+void wire_unpack2(Ctx &c, const u8 *packed, u64 count, u8 *dst);
 struct ResamplePart {
   const i64 *l_rank, *l_pos;
   u64 nl;

@@ -13,8 +13,9 @@ special ranks on the first of them, and a merge of two such blocks (reference in
      computes the new ranks it knows (left samples through its prefix sums, right samples through its chains) and a sum
      to the group's first GPU completes the merged sample set.
 
-Exchanged per merge and GPU: m bytes in (left L), about 4r/G bytes of g values and r/G bytes of right symbols through
-the all-to-alls, 16 bytes per sample; nothing is funnelled through one GPU.  The result is the same block the
+Exchanged per merge and GPU: the left L in (m bytes, or m/4 when the text's symbols span at most four values and
+L crosses the links as two bits per symbol), about 4r/G bytes of g values and r/G (or r/4G) bytes of right symbols
+through the all-to-alls, 8 bytes per sample.  The result is the same block the
 single-GPU recursion builds: L bit for bit (the slices concatenated), and the same samples, because the same tree is
 merged with the same rules.
 
@@ -62,20 +63,24 @@ class Comm:
         self.dist.all_gather(out, mine, group=self.group)
         return [[int(x) for x in t.cpu().tolist()] for t in out]
 
-    def all_to_all(self, send, send_splits, recv_splits):
-        """send: 1-D tensor cut into len(ranks) consecutive pieces of send_splits; returns the received pieces, by source."""
+    def all_to_all(self, send, send_splits, recv_splits, pad=0):
+        """send: 1-D tensor cut into len(ranks) consecutive pieces of send_splits; returns the received pieces, by source
+        (followed by `pad` unused elements)."""
         import torch
         src = self._wire(send).contiguous()
-        out = torch.empty(int(sum(recv_splits)), dtype=src.dtype, device=src.device)
-        self.dist.all_to_all_single(out, src, [int(x) for x in recv_splits], [int(x) for x in send_splits], group=self.group)
+        total = int(sum(recv_splits))
+        out = torch.empty(total + pad, dtype=src.dtype, device=src.device)
+        self.dist.all_to_all_single(out[:total], src, [int(x) for x in recv_splits], [int(x) for x in send_splits], group=self.group)
         return self._home(out)
 
-    def spread(self, pieces, out, offsets):
-        """pieces[j] (or None) is the tensor rank ranks[j] owns; afterwards out[offsets[j]:offsets[j+1]] holds it on every rank."""
+    def spread(self, pieces, out, offsets, sizes=None):
+        """pieces[j] (or None) is the tensor rank ranks[j] owns; afterwards out[offsets[j]:offsets[j+1]] holds it on every rank
+        (with `sizes`: out[offsets[j]:offsets[j]+sizes[j]], the pieces need not touch)."""
         import torch
         ops, stage = [], []
         for j, owner in enumerate(self.ranks):
-            lo, hi = offsets[j], offsets[j + 1]
+            lo = offsets[j]
+            hi = offsets[j + 1] if sizes is None else lo + sizes[j]
             if hi == lo:
                 continue
             if owner == self.me:
@@ -157,6 +162,23 @@ class HipDistOps:
         counts = self.ctx.dist_partition(g.data_ptr(), g.numel(), m, parts, out.data_ptr())
         return out, [int(x) for x in counts]
 
+    def wire_packable(self):
+        return self.ctx.dist_wire_packable()
+
+    def wire_pack(self, t):
+        n = int(t.numel())
+        out = self.empty(wire_bytes(n), self.torch.uint8)
+        if n:
+            self._ready()
+            self.ctx.dist_wire_pack(t.data_ptr(), n, out.data_ptr())
+        return out
+
+    def wire_unpack(self, packed, count, dst):
+        """dst[0:count) from the packed stream at the start of `packed`, which is followed by WIRE_PAD readable bytes."""
+        if count:
+            self._ready()
+            self.ctx.dist_wire_unpack(packed.data_ptr(), count, dst.data_ptr())
+
     def merge_slice(self, lL, rL, g_rel):
         mL, rn = int(lL.numel()), int(rL.numel())
         out = self.empty(mL + rn, self.torch.uint8)
@@ -177,6 +199,14 @@ class HipDistOps:
 
     def free_block(self, lb):
         lb.free()
+
+
+WIRE_PAD = 8  # bytes the unpacking kernel may read past a packed stream (BWT_HIP_WIRE_PAD)
+
+
+def wire_bytes(count):
+    """Bytes of `count` symbols at two bits each."""
+    return (int(count) + 3) // 4
 
 
 def _overlap(lo0, hi0, lo1, hi1):
@@ -207,7 +237,25 @@ def dist_merge(ops, comm, blk, ns_req):
     for x in lsizes:
         loff.append(loff[-1] + x)
     fullL = ops.empty(m, torch.uint8)
-    comm.spread([blk.L if (j < q and ranks[j] == me) else None for j in range(G)], fullL, loff + [m] * q)
+    packed_wire = ops.wire_packable()  # the same on every rank: they hold the same text
+    if not packed_wire:
+        comm.spread([blk.L if (j < q and ranks[j] == me) else None for j in range(G)], fullL, loff + [m] * q)
+    else:
+        # two bits per symbol on the wire: a quarter of the bytes of what is, at the top of the tree, the largest
+        # transfer of the build (every GPU receives the whole left block)
+        psz = [wire_bytes(x) for x in lsizes] + [0] * q
+        poff = [0]
+        for x in psz:
+            poff.append(poff[-1] + ((x + WIRE_PAD + 15) & ~15))
+        staged = ops.empty(poff[-1], torch.uint8)
+        comm.spread([ops.wire_pack(blk.L) if (j < q and ranks[j] == me) else None for j in range(G)], staged, poff, psz)
+        for j in range(q):
+            if ranks[j] == me:
+                fullL[loff[j]:loff[j + 1]].copy_(blk.L)
+            else:
+                ops.wire_unpack(staged[poff[j]:], lsizes[j], fullL[loff[j]:loff[j + 1]])
+        if a == 0:  # the block that starts at text position 0 holds the terminator at s_rank, which has no code
+            fullL[s_rank_l - a] = 0
     lb = ops.left_block(a, c, fullL, s_rank_l, e_rank_l)
 
     # 2. LF chains of this GPU's share of the right positions
@@ -236,7 +284,23 @@ def dist_merge(ops, comm, blk, ns_req):
         send_splits = [0] * G
         send = ops.empty(0, torch.uint8)
     recv_splits = [0] * q + [_overlap(roff[j], roff[j + 1], rb[k], rb[k + 1]) for j in range(q)]
-    rL = comm.all_to_all(send, send_splits, recv_splits)
+    if not packed_wire:
+        rL = comm.all_to_all(send, send_splits, recv_splits)
+    else:
+        pieces, at = [], 0
+        for d in range(G):
+            if send_splits[d]:
+                pieces.append(ops.wire_pack(send[at:at + send_splits[d]]))
+            at += send_splits[d]
+        send_pk = torch.cat(pieces) if pieces else ops.empty(0, torch.uint8)
+        got = comm.all_to_all(send_pk, [wire_bytes(x) for x in send_splits], [wire_bytes(x) for x in recv_splits], pad=WIRE_PAD)
+        rL = ops.empty(sum(recv_splits), torch.uint8)
+        at_b = at_s = 0
+        for d in range(G):
+            if recv_splits[d]:
+                ops.wire_unpack(got[at_b:], recv_splits[d], rL[at_s:at_s + recv_splits[d]])
+            at_b += wire_bytes(recv_splits[d])
+            at_s += recv_splits[d]
 
     # 4. this part's slice of the merged block
     lo = [int(x) for x in dist_bounds(m, G)]

@@ -204,6 +204,18 @@ int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l, int64_t ra, int64_t 
    part), each minus lo[part]; counts[k] = size of part k. */
 int bwt_hip_dist_partition(bwt_hip_ctx *ctx, const uint32_t *g_dev, int64_t count, int64_t m, int parts,
                            uint32_t *out_dev, int64_t *counts);
+/* Symbols between GPUs.  The blocks of a merge travel as they are in the reference's one address space
+   (include/bwt.h:791-847 reads l.L and r.L in place); between GPUs a stretch of L crosses the link as two bits
+   per symbol when the text allows it: *packable = 1 iff the text's symbols (the terminator aside) span at most
+   four consecutive values.  pack: `count` symbols at src_dev (any alignment) -> (count + 3) / 4 bytes at
+   packed_dev, code = (symbol - smallest symbol) & 3, first symbol in the lowest bits.  unpack: the reverse into
+   dst_dev (any alignment); it reads up to BWT_HIP_WIRE_PAD bytes past the packed stream, so the buffer that holds
+   one is that much longer.  The terminator, which the block that starts at text position 0 holds at s_rank, has no
+   code: the receiver puts it back. */
+#define BWT_HIP_WIRE_PAD 8
+int bwt_hip_dist_wire_packable(bwt_hip_ctx *ctx, int *packable);
+int bwt_hip_dist_wire_pack(bwt_hip_ctx *ctx, const uint8_t *src_dev, int64_t count, uint8_t *packed_dev);
+int bwt_hip_dist_wire_unpack(bwt_hip_ctx *ctx, const uint8_t *packed_dev, int64_t count, uint8_t *dst_dev);
 /* One part: lL_dev = the part's mL left symbols (rank order), rL_dev = its rn right symbols (rank order),
    g_dev = their rn insertion points relative to the part's first left rank, any order (destroyed).
    out_dev[0 : mL+rn) = the part's slice of the merged block; S_dev[i] (mL+1 entries) = right symbols of

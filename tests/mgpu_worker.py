@@ -83,6 +83,25 @@ class NumpyDistOps:
     def left_block(self, a, c, L, s_rank, e_rank):
         return (a, c)
 
+    # two bits per symbol on the wire, as include/bwt_hip.h defines them: code = (symbol - smallest symbol) & 3,
+    # four symbols per byte, the first in the lowest bits
+    def _min_sym(self):
+        return int(self.T[self.T > 0].min())
+
+    def wire_packable(self):
+        body = self.T[self.T > 0]
+        return int(body.max()) - int(body.min()) <= 3
+
+    def wire_pack(self, t):
+        v = ((t.numpy().astype(np.int64) - self._min_sym()) & 3).astype(np.uint8)
+        v = np.concatenate([v, np.zeros(-len(v) % 4, dtype=np.uint8)]).reshape(-1, 4)
+        return self.torch.from_numpy((v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8))
+
+    def wire_unpack(self, packed, count, dst):
+        p = packed.numpy()[:(count + 3) // 4]
+        codes = np.stack([(p >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)[:count]
+        dst.copy_(self.torch.from_numpy((codes + self._min_sym()).astype(np.uint8)))
+
     def free_block(self, lb):
         pass
 

@@ -36,6 +36,13 @@ def test_native_multi_other_texts():
     assert _same_as_oracle(gen_text(150000, 7, 255), 255, 4, 20000, 2000) == 4
     assert _same_as_oracle(gen_text(99991, 9, 26), 26, 8, 7000, 500, 333) == 8
     assert _same_as_oracle(gen_repetitive(3000, 30, 0.001, seed=43, sigma=4), 4, 4, 12000, 700) == 4
+    # L crosses between the ranks as two bits per symbol whenever the symbols span at most four values: letters
+    # that are not 1..4, an alphabet of three, and lengths that leave every slice at an odd offset
+    T = gen_text(123457, 5, 4)
+    T[:-1] += 100
+    assert _same_as_oracle(T, 104, 8, 123457 // 8 + 1, 900) == 8
+    assert _same_as_oracle(gen_text(77773, 6, 3), 3, 4, 77773 // 8 + 1, 555, 50) == 4
+    assert _same_as_oracle(gen_text(1001, 8, 2), 2, 8, 1001 // 8 + 1, 40, 16) == 8
     # skewed: nearly all right suffixes fall into few gaps, parts of very different sizes
     T = np.concatenate([gen_text(6001, 3, 4)[:-1], np.full(5999, 2, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
     assert _same_as_oracle(T, 4, 8, 1000, 300, 64) == 8

@@ -77,20 +77,23 @@ def test_dist_bounds_partition_the_left_ranks():
         assert (m * scale) >> 32 < parts
 
 
-@pytest.mark.parametrize("world,lpr,direct", [(2, 1, 0), (4, 1, 0), (4, 2, 1), (8, 1, 1), (2, 1, 1)])
-def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr, direct):
+@pytest.mark.parametrize("world,lpr,direct,sigma", [(2, 1, 0, 4), (4, 1, 0, 4), (4, 2, 1, 4), (8, 1, 1, 4), (2, 1, 1, 4),
+                                                    (4, 1, 1, 6), (2, 2, 0, 3)])
+def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr, direct, sigma):
     """Every merge spread over all ranks of its subtree (bwt_amd/dist_merge.py), the per-part steps done in numpy:
     the exchange pattern and the bookkeeping are what is tested; the result must be the block of the same tree.
     direct = 1 hands the tensors to the transport without host staging: receives land in slices of the destination
-    buffer, broadcasts and sums work in place -- the code path of an nccl run."""
-    n, ns, seg = 24000, 300, 64
+    buffer, broadcasts and sums work in place -- the code path of an nccl run.  Alphabets of up to four symbols send
+    L as two bits per symbol (slices of any length and offset, the terminator of the first block put back); six
+    symbols take the plain bytes."""
+    n, ns, seg = 24000 + sigma, 300, 64
     out = str(tmp_path / "res.npz")
     _launch(world, ["--ops", "oracle", "--algo", "dist", "--text_len", str(n), "--lpr", str(lpr), "--ns", str(ns),
-                    "--seg", str(seg), "--direct", str(direct)], out)
+                    "--seg", str(seg), "--direct", str(direct), "--sigma", str(sigma)], out)
     res = np.load(out)
-    T = gen_text(n, 42, 4)
+    T = gen_text(n, 42, sigma)
     th = multi_gpu.leaf_threshold(n, world * lpr)
-    o = Oracle.opt(n, alpha_min=1, alpha_max=4, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
     ob = Oracle.pmbwt(T, o)
     assert (res["L"] == ob.L).all()
     assert (int(res["s_rank"]), int(res["e_rank"])) == (ob.s_rank, ob.e_rank)
