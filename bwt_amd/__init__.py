@@ -77,7 +77,9 @@ def lib():
         "bwt_hip_dist_wire_unpack": [vp, vp, i64, vp],
         "bwt_hip_dist_merge_slice": [vp, vp, i64, vp, i64, vp, vp, vp],
         "bwt_hip_dist_merge_slice_noalloc": [vp, vp, i64, vp, i64, vp, vp, vp],
-        "bwt_hip_dist_resample": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, vp, vp, _i64p],
+        "bwt_hip_dist_samples_route": [vp, i32, vp, vp, i64, i64, i64, i64, i64, i32, vp, vp, _i64p],
+        "bwt_hip_dist_samples_answer": [vp, vp, i64, i64, vp, i64, i64, i64, vp, vp],
+        "bwt_hip_dist_samples_place": [vp, i32, vp, vp, i64, vp, vp, i64, i64, i64, i64, i64, vp, vp, _i64p],
         "bwt_hip_set_timing": [vp, i32],
         "bwt_hip_reset_timers": [vp],
         "bwt_hip_timer_count": [vp],
@@ -369,16 +371,26 @@ class Context:
         _chk(lib().bwt_hip_dist_merge_slice_noalloc(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),
                                                     C.c_void_p(out_ptr), C.c_void_p(S_ptr)))
 
-    def dist_resample(self, l_rank_ptr, l_pos_ptr, nl, r_rank_ptr, r_pos_ptr, nr, a, c, ns_out, S_ptr, i_lo, i_hi,
-                      right_before, g_ptr, p_lo, p_hi, o_rank_ptr, o_pos_ptr):
-        kept = C.c_int64(0)
+    def dist_samples_route(self, is_left, rank_ptr, pos_ptr, n, a, c, m, r, members, queries_ptr, perm_ptr):
         vp = C.c_void_p
-        _chk(lib().bwt_hip_dist_resample(self._h, vp(l_rank_ptr), vp(l_pos_ptr), nl, vp(r_rank_ptr), vp(r_pos_ptr), nr, a, c,
-                                         ns_out, vp(S_ptr), i_lo, i_hi, right_before, vp(g_ptr), p_lo, p_hi,
-                                         vp(o_rank_ptr), vp(o_pos_ptr), C.byref(kept)))
+        counts = np.zeros(members, dtype=np.int64)
+        _chk(lib().bwt_hip_dist_samples_route(self._h, int(is_left), vp(rank_ptr), vp(pos_ptr), n, a, c, m, r, members,
+                                              vp(queries_ptr), vp(perm_ptr), _p(counts, _i64p)))
+        return counts
+
+    def dist_samples_answer(self, queries_ptr, n_left, n_right, S_ptr, i_lo, right_before, a, g_ptr, answers_ptr):
+        vp = C.c_void_p
+        _chk(lib().bwt_hip_dist_samples_answer(self._h, vp(queries_ptr), n_left, n_right, vp(S_ptr), i_lo, right_before, a,
+                                               vp(g_ptr), vp(answers_ptr)))
+
+    def dist_samples_place(self, is_left, rank_ptr, pos_ptr, n, answers_ptr, perm_ptr, a, c, first_index, n_all, ns_out,
+                           o_rank_ptr, o_pos_ptr):
+        vp = C.c_void_p
+        kept = C.c_int64(0)
+        _chk(lib().bwt_hip_dist_samples_place(self._h, int(is_left), vp(rank_ptr), vp(pos_ptr), n, vp(answers_ptr), vp(perm_ptr),
+                                              a, c, first_index, n_all, ns_out, vp(o_rank_ptr), vp(o_pos_ptr), C.byref(kept)))
         return kept.value
 
-    # ---- observability ----------------------------------------------------
     def set_timing(self, level):
         _chk(lib().bwt_hip_set_timing(self._h, level))
 

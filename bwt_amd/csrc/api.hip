@@ -895,44 +895,58 @@ int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
   API_END
 }
 
-int bwt_hip_dist_resample(bwt_hip_ctx *ctx, const int64_t *l_rank_dev, const int64_t *l_pos_dev, int64_t nl,
-                          const int64_t *r_rank_dev, const int64_t *r_pos_dev, int64_t nr, int64_t a, int64_t cpos,
-                          int64_t ns_out, const uint32_t *S_dev, int64_t i_lo, int64_t i_hi, int64_t right_before,
-                          const uint32_t *g_dev, int64_t p_lo, int64_t p_hi, int64_t *o_rank_dev, int64_t *o_pos_dev,
-                          int64_t *kept) {
+int bwt_hip_dist_samples_route(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
+                               int64_t a, int64_t cpos, int64_t m, int64_t r, int members, uint32_t *queries_dev,
+                               uint32_t *perm_dev, int64_t *counts) {
   API_BEGIN
-  need(ctx && kept && nl >= 0 && nr >= 0 && ns_out >= 1, "ctx, kept, nl >= 0, nr >= 0, ns_out >= 1");
+  need(ctx && counts && n >= 0 && members >= 1 && members <= 256, "ctx, counts, n >= 0, 1 <= members <= 256");
+  need(n == 0 || (queries_dev && (is_left ? (rank_dev && perm_dev) : pos_dev != nullptr)), "device buffers");
   Ctx &c = ctx->c;
   HIP_CHECK(hipSetDevice(c.device));
-  const u64 nn = (u64)(nl + nr);
-  ResamplePart R;
-  R.l_rank = l_rank_dev;
-  R.l_pos = l_pos_dev;
-  R.nl = (u64)nl;
-  R.r_rank = r_rank_dev;
-  R.r_pos = r_pos_dev;
-  R.nr = (u64)nr;
-  R.a = a;
-  R.cc = cpos;
-  R.A = (u64)(ns_out - 1);
-  R.B = nn ? nn - 1 : 0;
-  R.S_local = S_dev;
-  R.i_lo = (u64)i_lo;
-  R.i_hi = (u64)i_hi;
-  R.right_before = (u64)right_before;
-  R.g_local = g_dev;
-  R.p_lo = (u64)p_lo;
-  R.p_hi = (u64)p_hi;
-  R.o_rank = o_rank_dev;
-  R.o_pos = o_pos_dev;
-  u64 k = nn;
-  if (nn >= 1) {
-    u64 t = 1 + (R.B ? ((nn - 1) * R.A) / R.B : 0);
-    k = t < nn ? t : nn;
-  }
-  *kept = (i64)k;
-  if (o_rank_dev && o_pos_dev) {
-    resample_part(c, R);
+  if (is_left) samples_route_left(c, rank_dev, (u64)n, a, (u64)m, (u32)members, queries_dev, perm_dev, counts);
+  else samples_route_right(c, pos_dev, (u64)n, cpos, (u64)r, (u32)members, queries_dev, counts);
+  API_END
+}
+
+int bwt_hip_dist_samples_answer(bwt_hip_ctx *ctx, const uint32_t *queries_dev, int64_t n_left, int64_t n_right,
+                                const uint32_t *S_dev, int64_t i_lo, int64_t right_before, int64_t a, const uint32_t *g_dev,
+                                uint32_t *answers_dev) {
+  API_BEGIN
+  need(ctx && n_left >= 0 && n_right >= 0, "ctx, n_left >= 0, n_right >= 0");
+  need(n_left + n_right == 0 || (queries_dev && answers_dev), "queries_dev, answers_dev");
+  need((n_left == 0 || S_dev) && (n_right == 0 || g_dev), "S_dev, g_dev");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  samples_answer(c, queries_dev, (u64)n_left, (u64)n_right, S_dev, (u64)i_lo, (u64)right_before, a, g_dev, answers_dev);
+  c.sync();
+  API_END
+}
+
+int bwt_hip_dist_samples_place(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
+                               const uint32_t *answers_dev, const uint32_t *perm_dev, int64_t a, int64_t cpos,
+                               int64_t first_index, int64_t n_all, int64_t ns_out, uint32_t *o_rank_dev, uint32_t *o_pos_dev,
+                               int64_t *kept) {
+  API_BEGIN
+  need(ctx && kept && n >= 0 && first_index >= 0 && first_index + n <= n_all && ns_out >= 1, "ctx, kept, 0 <= first_index, first_index + n <= n_all, ns_out >= 1");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  SamplePlace P;
+  P.A = (u64)(ns_out - 1);
+  P.B = n_all ? (u64)(n_all - 1) : 0;
+  P.first_index = (u64)first_index;
+  P.first_slot = samples_taken_before(P.first_index, P.A, P.B);
+  *kept = (i64)(samples_taken_before(P.first_index + (u64)n, P.A, P.B) - P.first_slot);
+  if (o_rank_dev && o_pos_dev && n > 0) {
+    need(rank_dev && pos_dev && answers_dev && (!is_left || perm_dev), "device buffers");
+    P.rank = rank_dev;
+    P.pos = pos_dev;
+    P.n = (u64)n;
+    P.ans = answers_dev;
+    P.perm = is_left ? perm_dev : nullptr;
+    P.right_shift = is_left ? 0u : (u32)(cpos - a);
+    P.o_rank = o_rank_dev;
+    P.o_pos = o_pos_dev;
+    samples_place(c, P);
     c.sync();
   }
   API_END

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(PT_THREADS)
 // its part.  cursors[k] starts as the first output index of part k.
 __global__ void __launch_bounds__(PT_THREADS)
     k_part_scatter(const u32 *__restrict__ in, u64 count, u64 scale, u32 parts, const u32 *__restrict__ part_lo,
-                   unsigned long long *__restrict__ cursors, u32 *__restrict__ out) {
+                   unsigned long long *__restrict__ cursors, u32 *__restrict__ out, u32 *__restrict__ perm) {
   __shared__ u32 cnt[PT_MAX_PARTS];
   __shared__ unsigned long long start[PT_MAX_PARTS];
   const u32 tid = threadIdx.x;
@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(PT_THREADS)
     if (i < count) {
       u32 p = part_of(v[k], scale);
       out[start[p] + slot[k]] = v[k] - part_lo[p];
+      if (perm) perm[start[p] + slot[k]] = (u32)i;  // where the value came from
     }
   }
 }
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(PT_THREADS)
 // first value v with part(v) >= k
 static u64 part_lower_bound(u64 k, u64 scale) { return ((k << 32) + scale - 1) / scale; }
 
-void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host) {
+void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm) {
   if (parts < 1 || parts > PT_MAX_PARTS) fail(BWT_HIP_EINVAL, "partition: 1..%d parts", PT_MAX_PARTS);
   const u64 scale = (((u64)parts) << 32) / (m + 1);
   DBuf<unsigned long long> d(c, 2 * (size_t)parts);
@@ -98,7 +99,7 @@ void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, 
   if (count > 0) {
     HIP_CHECK(hipMemcpyAsync(d.get() + parts, h_cur, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, c.stream));
     hipLaunchKernelGGL(k_part_scatter, dim3(nblk), dim3(PT_THREADS), 0, c.stream, in, count, scale, parts, lo.get(),
-                       d.get() + parts, out);
+                       d.get() + parts, out, perm);
     HIP_CHECK(hipGetLastError());
     c.sync();  // h_cur is on the stack
   }
@@ -182,15 +183,8 @@ void partition_bounds(u64 m, u32 parts, i64 *lo_out) {
   lo_out[parts] = (i64)(m + 1);
 }
 
-// ----------------------------------------------------------------------------
-// this GPU's share of the merged block's samples (reference: include/bwt.h:366-453
-// resample_sa; selection rule as in k_resample of merge.hip).  Sample i of the
-// concatenation (left samples by position, then right samples by position) is
-// handled by the GPU that knows its new rank: a left sample by the owner of its
-// left rank, a right sample by the GPU whose chains covered its position.  Kept
-// samples are written to their slot; the caller sums the arrays of all GPUs.
-// Ranks are block-relative plus the block's first position, as everywhere in the C interface.
-// ----------------------------------------------------------------------------
+// samples kept among the first i of a merge's sample sequence (left samples by position, then right samples by
+// position): the reference's serial selection (include/bwt.h:412, :436) in closed form, as in k_resample of merge.hip
 __device__ __forceinline__ u64 taken_before_d(u64 i, u64 A, u64 B) {
   if (i == 0) return 0;
   if (B == 0) return 1;
@@ -198,29 +192,119 @@ __device__ __forceinline__ u64 taken_before_d(u64 i, u64 A, u64 B) {
   return t < i ? t : i;
 }
 
-__global__ void k_resample_part(ResamplePart R) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R.nl + R.nr) return;
-  u64 t0 = taken_before_d(i, R.A, R.B), t1 = taken_before_d(i + 1, R.A, R.B);
-  if (t1 == t0) return;
-  if (i < R.nl) {
-    u64 rk = (u64)(R.l_rank[i] - R.a);
-    if (rk < R.i_lo || rk >= R.i_hi) return;
-    R.o_rank[t0] = R.a + (i64)(rk + R.right_before + R.S_local[rk - R.i_lo]);
-    R.o_pos[t0] = R.l_pos[i];
-  } else {
-    u64 k = i - R.nl;
-    u64 p = (u64)R.r_pos[k];
-    if (p < R.p_lo || p >= R.p_hi) return;
-    R.o_rank[t0] = R.a + (R.r_rank[k] - R.cc) + (i64)R.g_local[p - R.p_lo];
-    R.o_pos[t0] = R.r_pos[k];
-  }
+// ----------------------------------------------------------------------------
+// The samples stay where they are.  Every member of a block keeps the samples whose positions lie
+// in the text range it built its own subtree on (sorted by position; members in order = the block's samples in
+// order).  In a merge a sample does not move: its holder asks the member that knows for the one number the new
+// rank needs -- for a left sample the owner of its left rank's part (prefix sums), for a right sample the member
+// whose chains covered its position (g) -- gets it back, and thins its own samples by the reference's rule, which
+// depends on a sample's index in the whole sequence only.  4 bytes out and 4 bytes back per sample.
+// ----------------------------------------------------------------------------
+__global__ void k_rel_u32(const u32 *__restrict__ in, u64 n, u32 base, u32 *__restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] - base;
 }
 
-void resample_part(Ctx &c, const ResamplePart &R) {
-  u64 nn = R.nl + R.nr;
-  if (nn == 0) return;
-  hipLaunchKernelGGL(k_resample_part, dim3(ceil_div(nn, 256)), dim3(256), 0, c.stream, R);
+// first index of the ascending array v[0:n) whose value is >= bound[t], for t in [0, nb)
+__global__ void k_lower_bounds(const u32 *__restrict__ v, u32 n, const u32 *__restrict__ bound, u32 nb, u32 *__restrict__ out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb) return;
+  u32 lo = 0, hi = n;
+  const u32 b = bound[t];
+  while (lo < hi) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (v[mid] < b) lo = mid + 1;
+    else hi = mid;
+  }
+  out[t] = lo;
+}
+
+// queries of a right holder: sample i asks member d, the one with first[d] <= i < first[d+1], for g at pos[i] - bound[d]
+__global__ void k_right_queries(const u32 *__restrict__ pos, u32 n, const u32 *__restrict__ bound, const u32 *__restrict__ first,
+                                u32 members, u32 *__restrict__ q) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 lo = 0, hi = members;  // the last d with first[d] <= i
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) / 2;
+    if (first[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  q[i] = pos[i] - bound[lo];
+}
+
+// answers of one member: n_left look-ups into its part's prefix sums, then n_right into its chains' g values
+__global__ void k_sample_answers(const u32 *__restrict__ q, u64 n_left, u64 n_right, const u32 *__restrict__ S_local, u32 left_base,
+                                 const u32 *__restrict__ g_local, u32 *__restrict__ ans) {
+  const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_left + n_right) return;
+  const u32 v = q[x];
+  // left: new rank = a + rk + (right suffixes in lower parts) + S'[rk - i_lo], with left_base = a + i_lo + right_before
+  ans[x] = x < n_left ? left_base + v + S_local[v] : g_local[v];
+}
+
+__global__ void k_sample_place(SamplePlace P) {
+  const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= P.n) return;
+  const u64 i = P.perm ? P.perm[x] : x;  // answer x belongs to the holder's sample i
+  const u64 gi = P.first_index + i;
+  const u64 t0 = taken_before_d(gi, P.A, P.B), t1 = taken_before_d(gi + 1, P.A, P.B);
+  if (t1 == t0) return;
+  const u64 slot = t0 - P.first_slot;
+  // left: the answer is the new rank; right: rank in the right block + g, include/bwt.h:778-781 then :437
+  P.o_rank[slot] = P.right_shift ? P.rank[i] - P.right_shift + P.ans[x] : P.ans[x];
+  P.o_pos[slot] = P.pos[i];
+}
+
+u64 samples_taken_before(u64 i, u64 A, u64 B) {
+  if (i == 0) return 0;
+  if (B == 0) return 1;
+  const u64 t = 1 + (u64)(((unsigned __int128)(i - 1) * A) / B);
+  return t < i ? t : i;
+}
+
+void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts) {
+  DBuf<u32> rel(c, n ? n : 1);
+  if (n) {
+    hipLaunchKernelGGL(k_rel_u32, dim3(ceil_div(n, 256)), dim3(256), 0, c.stream, rank_abs, n, (u32)a, rel.get());
+    HIP_CHECK(hipGetLastError());
+  }
+  partition_by_left_rank(c, rel.get(), n, m, members, queries, counts, perm);
+  c.sync();
+}
+
+void samples_route_right(Ctx &c, const u32 *pos, u64 n, i64 cpos, u64 r, u32 members, u32 *queries, i64 *counts) {
+  if (members < 1 || members > PT_MAX_PARTS) fail(BWT_HIP_EINVAL, "samples: 1..%d members", PT_MAX_PARTS);
+  u32 h_bound[PT_MAX_PARTS + 1], h_first[PT_MAX_PARTS + 1];
+  for (u32 d = 0; d <= members; d++) h_bound[d] = (u32)((u64)cpos + (u64)(((unsigned __int128)d * r) / members));
+  DBuf<u32> d_tab(c, 2 * (size_t)(members + 1));
+  HIP_CHECK(hipMemcpyAsync(d_tab.get(), h_bound, (members + 1) * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(k_lower_bounds, dim3(ceil_div(members + 1, 256)), dim3(256), 0, c.stream, pos, (u32)n, (const u32 *)d_tab.get(),
+                     members + 1, d_tab.get() + (members + 1));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_first, d_tab.get() + (members + 1), (members + 1) * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  if (h_first[0] != 0 || h_first[members] != (u32)n) fail(BWT_HIP_EINTERNAL, "samples: a right sample lies outside [%ld, %ld)", (long)cpos, (long)(cpos + (i64)r));
+  for (u32 d = 0; d < members; d++) counts[d] = (i64)h_first[d + 1] - (i64)h_first[d];
+  if (n) {
+    hipLaunchKernelGGL(k_right_queries, dim3(ceil_div(n, 256)), dim3(256), 0, c.stream, pos, (u32)n, (const u32 *)d_tab.get(),
+                       (const u32 *)(d_tab.get() + (members + 1)), members, queries);
+    HIP_CHECK(hipGetLastError());
+  }
+  c.sync();  // the table dies here
+}
+
+void samples_answer(Ctx &c, const u32 *q, u64 n_left, u64 n_right, const u32 *S_local, u64 i_lo, u64 right_before, i64 a,
+                    const u32 *g_local, u32 *ans) {
+  if (n_left + n_right == 0) return;
+  hipLaunchKernelGGL(k_sample_answers, dim3(ceil_div(n_left + n_right, 256)), dim3(256), 0, c.stream, q, n_left, n_right, S_local,
+                     (u32)((u64)a + i_lo + right_before), g_local, ans);
+  HIP_CHECK(hipGetLastError());
+}
+
+void samples_place(Ctx &c, const SamplePlace &P) {
+  if (P.n == 0) return;
+  hipLaunchKernelGGL(k_sample_place, dim3(ceil_div(P.n, 256)), dim3(256), 0, c.stream, P);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -2,7 +2,8 @@
 //
 // The recursion tree of bwt_rec (reference include/bwt.h:854-865: split at (a+b)/2) is cut at depth
 // log2(world); rank k builds subtree k on its own GPU.  A block of the tree that spans q ranks stays spread
-// over them as q slices of its L (rank ranges), its samples and special ranks on the first of them.  A merge
+// over them as q slices of its L (rank ranges); each keeps the block's samples whose positions lie in its own
+// text range; s_rank is known to the first of them, e_rank to the last.  A merge
 // of two such blocks (include/bwt.h:791-847) runs on all G = 2q ranks:
 //   1. every rank receives the left block's L (each holder sends its slice to all others) and builds the
 //      left rank structure;
@@ -11,8 +12,9 @@
 //   3. the merge is cut by left rank into G parts (partition_bounds): one all-to-all moves every g value
 //      to the rank that owns its part, a second one the right symbols that part interleaves;
 //   4. every rank builds its part's prefix sums and writes its slice of the merged L;
-//   5. both sample sets go to every rank, each places the samples whose new rank it knows, the group's
-//      first rank collects them.
+//   5. the samples do not move: every rank keeps those of its own text range, asks the rank that knows for
+//      the number each new rank needs (the part's prefix sums for a left sample, g for a right one) and thins
+//      its own by the reference's rule.
 // Same tree, same rules: the slices concatenated are the L of the single-GPU build, bit for bit.
 //
 // Ranks move device memory through a bwt_hip_transport (one primitive: a batch of sends and receives).  Two
@@ -59,17 +61,9 @@ static bool tree_reaches(i64 n, i64 th, int depth) {
 // ---------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------
-__global__ void k_add_u32(u32 *__restrict__ acc, const u32 *__restrict__ x, u64 n) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) acc[i] += x[i];
-}
 __global__ void k_u32_to_i64(const u32 *__restrict__ in, u64 n, i64 *__restrict__ out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (i64)in[i];
-}
-__global__ void k_i64_to_u32(const i64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (u32)in[i];
 }
 __global__ void k_abs_ranks(const u32 *__restrict__ rel, u64 n, u32 a, u32 *__restrict__ out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,9 +85,9 @@ struct DistBlock {
   int first = 0, q = 1;       // held by the ranks first .. first+q-1
   std::vector<i64> sizes;     // symbols of every holder's slice
   DBuf<u8> L;                 // this rank's slice
-  i64 s_rank = -1, e_rank = -1;  // absolute; on rank `first` only
-  DBuf<u32> samp_rank, samp_pos; // absolute ranks, positions; on rank `first` only
-  i64 n_samp = 0;
+  i64 s_rank = -1, e_rank = -1;  // absolute; s_rank on the first holder only, e_rank on the last only
+  DBuf<u32> samp_rank, samp_pos; // absolute ranks, positions: the block's samples inside this rank's own text range, by position
+  i64 n_samp = 0;                // of this rank
 };
 
 struct Group {
@@ -147,33 +141,6 @@ struct Group {
       HIP_CHECK(hipMemcpyAsync(recv + my_ro, send + my_so, (size_t)send_bytes[(size_t)k], hipMemcpyDeviceToDevice, c.stream));
     exchange(ops);
   }
-
-  // buf (bytes) on member `root` reaches every member
-  void broadcast(void *buf, i64 bytes, int root) {
-    std::vector<bwt_hip_p2p> ops;
-    if (k == root) {
-      for (int j = 0; j < G; j++)
-        if (j != k) ops.push_back({first + j, 1, buf, bytes});
-    } else {
-      ops.push_back({first + root, 0, buf, bytes});
-    }
-    exchange(ops);
-  }
-
-  // acc[0:n) on member 0 += the arrays of all other members (whose entries are zero where they placed nothing)
-  void sum_to_first(u32 *acc, u64 n) {
-    if (n == 0) return;
-    if (k != 0) {
-      std::vector<bwt_hip_p2p> ops{{first, 1, acc, (i64)n * 4}};
-      exchange(ops);
-      return;
-    }
-    DBuf<u32> in(c, (size_t)n * (size_t)(G - 1));
-    std::vector<bwt_hip_p2p> ops;
-    for (int j = 1; j < G; j++) ops.push_back({first + j, 0, in.get() + (size_t)n * (size_t)(j - 1), (i64)n * 4});
-    exchange(ops);
-    for (int j = 1; j < G; j++) launch1d(c, k_add_u32, n, acc, (const u32 *)(in.get() + (size_t)n * (size_t)(j - 1)), n);
-  }
 };
 
 static i64 overlap(i64 lo0, i64 hi0, i64 lo1, i64 hi1) {
@@ -196,7 +163,7 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   for (int j = 0; j < q; j++) loff.push_back(loff.back() + M(j, 5));
   for (int j = 0; j < q; j++) roff.push_back(roff.back() + M(q + j, 5));
   if (loff.back() != m || roff.back() != r) fail(BWT_HIP_EINTERNAL, "slice sizes do not add up to the blocks");
-  const i64 s_rank_l = M(0, 2), e_rank_l = M(0, 3), nl = M(0, 4), nr = M(q, 4);
+  const i64 s_rank_l = M(0, 2), e_rank_l = M(q - 1, 3);
 
   // 1. the left block's L on every member
   std::unique_ptr<Block> lb(new Block());
@@ -319,73 +286,63 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
     merge_symbols(c, lb->L.get() + i_lo, (u64)mL, rL.get(), (u64)rn, S.get(), out->L.get());
   }
 
-  // 5. samples: both sets to every member (32-bit words on the wire), each places what it can, the first collects
-  DBuf<u32> w_lr(c, (size_t)(nl ? nl : 1)), w_lp(c, (size_t)(nl ? nl : 1)), w_rr(c, (size_t)(nr ? nr : 1)), w_rp(c, (size_t)(nr ? nr : 1));
-  if (k == 0) {
-    HIP_CHECK(hipMemcpyAsync(w_lr.get(), blk->samp_rank.get(), (size_t)nl * 4, hipMemcpyDeviceToDevice, c.stream));
-    HIP_CHECK(hipMemcpyAsync(w_lp.get(), blk->samp_pos.get(), (size_t)nl * 4, hipMemcpyDeviceToDevice, c.stream));
-  }
-  if (k == q) {
-    HIP_CHECK(hipMemcpyAsync(w_rr.get(), blk->samp_rank.get(), (size_t)nr * 4, hipMemcpyDeviceToDevice, c.stream));
-    HIP_CHECK(hipMemcpyAsync(w_rp.get(), blk->samp_pos.get(), (size_t)nr * 4, hipMemcpyDeviceToDevice, c.stream));
-  }
-  g.broadcast(w_lr.get(), nl * 4, 0);
-  g.broadcast(w_lp.get(), nl * 4, 0);
-  g.broadcast(w_rr.get(), nr * 4, q);
-  g.broadcast(w_rp.get(), nr * 4, q);
-  const u64 nn = (u64)(nl + nr);
-  const i64 ns_out = ns_req < m + r ? ns_req : m + r;
-  u64 kept = nn;
-  if (nn >= 1) {
-    const u64 t = 1 + (nn > 1 ? ((nn - 1) * (u64)(ns_out - 1)) / (nn - 1) : 0);  // as k_resample selects: A = ns_out-1, B = nn-1
-    kept = t < nn ? t : nn;
-  }
-  DBuf<u32> o_rank(c, (size_t)(kept ? kept : 1)), o_pos(c, (size_t)(kept ? kept : 1));
+  // 5. samples stay with their holders: requests out, answers back, each holder thins its own
   {
-    DBuf<i64> lr(c, (size_t)(nl ? nl : 1)), lp(c, (size_t)(nl ? nl : 1)), rr(c, (size_t)(nr ? nr : 1)), rp(c, (size_t)(nr ? nr : 1));
-    DBuf<i64> orank(c, (size_t)(kept ? kept : 1)), opos(c, (size_t)(kept ? kept : 1));
-    launch1d(c, k_u32_to_i64, (u64)nl, (const u32 *)w_lr.get(), (u64)nl, lr.get());
-    launch1d(c, k_u32_to_i64, (u64)nl, (const u32 *)w_lp.get(), (u64)nl, lp.get());
-    launch1d(c, k_u32_to_i64, (u64)nr, (const u32 *)w_rr.get(), (u64)nr, rr.get());
-    launch1d(c, k_u32_to_i64, (u64)nr, (const u32 *)w_rp.get(), (u64)nr, rp.get());
-    HIP_CHECK(hipMemsetAsync(orank.get(), 0, (size_t)(kept ? kept : 1) * 8, c.stream));
-    HIP_CHECK(hipMemsetAsync(opos.get(), 0, (size_t)(kept ? kept : 1) * 8, c.stream));
-    ResamplePart P;
-    P.l_rank = lr.get();
-    P.l_pos = lp.get();
-    P.nl = (u64)nl;
-    P.r_rank = rr.get();
-    P.r_pos = rp.get();
-    P.nr = (u64)nr;
-    P.a = a;
-    P.cc = cpos;
-    P.A = (u64)(ns_out - 1);
-    P.B = nn ? nn - 1 : 0;
-    P.S_local = S.get();
-    P.i_lo = (u64)i_lo;
-    P.i_hi = (u64)i_hi;
-    P.right_before = (u64)rb[(size_t)k];
-    P.g_local = gt.get();
-    P.p_lo = (u64)p_lo;
-    P.p_hi = (u64)p_hi;
-    P.o_rank = orank.get();
-    P.o_pos = opos.get();
-    resample_part(c, P);
-    launch1d(c, k_i64_to_u32, kept, (const i64 *)orank.get(), kept, o_rank.get());
-    launch1d(c, k_i64_to_u32, kept, (const i64 *)opos.get(), kept, o_pos.get());
+    u64 nl = 0, nr = 0, first_index = 0;
+    for (int j = 0; j < G; j++) {
+      if (j < k) first_index += (u64)M(j, 4);
+      (j < q ? nl : nr) += (u64)M(j, 4);
+    }
+    const u64 nn = nl + nr, mine = (u64)blk->n_samp;
+    const i64 ns_out = ns_req < m + r ? ns_req : m + r;
+    const u64 A = (u64)(ns_out - 1), B = nn ? nn - 1 : 0;
+    DBuf<u32> queries(c, mine ? mine : 1), perm(c, mine ? mine : 1);
+    std::vector<i64> ask((size_t)G, 0);
+    if (k < q) samples_route_left(c, blk->samp_rank.get(), mine, a, (u64)m, (u32)G, queries.get(), perm.get(), ask.data());
+    else samples_route_right(c, blk->samp_pos.get(), mine, cpos, (u64)r, (u32)G, queries.get(), ask.data());
+    std::vector<i64> asked = g.all_gather(ask);  // asked[src * G + member]
+    u64 in_left = 0, in_right = 0;
+    std::vector<i64> ask_b((size_t)G), asked_b((size_t)G);
+    for (int j = 0; j < G; j++) {
+      const i64 x = asked[(size_t)j * (size_t)G + (size_t)k];
+      (j < q ? in_left : in_right) += (u64)x;
+      asked_b[(size_t)j] = x * 4;
+      ask_b[(size_t)j] = ask[(size_t)j] * 4;
+    }
+    const u64 in_all = in_left + in_right;
+    DBuf<u32> q_in(c, in_all ? in_all : 1), a_out(c, in_all ? in_all : 1), a_in(c, mine ? mine : 1);
+    g.all_to_all((const u8 *)queries.get(), ask_b, (u8 *)q_in.get(), asked_b);
+    samples_answer(c, q_in.get(), in_left, in_right, S.get(), (u64)i_lo, (u64)rb[(size_t)k], a, gt.get(), a_out.get());
+    g.all_to_all((const u8 *)a_out.get(), asked_b, (u8 *)a_in.get(), ask_b);
+    const u64 first_slot = samples_taken_before(first_index, A, B);
+    const u64 kept = samples_taken_before(first_index + mine, A, B) - first_slot;
+    DBuf<u32> o_rank(c, kept ? kept : 1), o_pos(c, kept ? kept : 1);
+    SamplePlace P;
+    P.rank = blk->samp_rank.get();
+    P.pos = blk->samp_pos.get();
+    P.n = mine;
+    P.ans = a_in.get();
+    P.perm = k < q ? perm.get() : nullptr;
+    P.right_shift = k < q ? 0u : (u32)m;
+    P.first_index = first_index;
+    P.first_slot = first_slot;
+    P.A = A;
+    P.B = B;
+    P.o_rank = o_rank.get();
+    P.o_pos = o_pos.get();
+    samples_place(c, P);
+    // the block's first sample is at position a (the first holder's first), its last at b - 1 (the last holder's last)
+    if (k == 0 || k == G - 1) {
+      if (kept == 0) fail(BWT_HIP_EINTERNAL, "merge [%ld,%ld): member %d kept no sample", (long)a, (long)b, k);
+      const u64 at = k == 0 ? 0 : kept - 1;
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars, o_rank.get() + at, 4, hipMemcpyDeviceToHost, c.stream));
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars + 1, o_pos.get() + at, 4, hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      if ((i64)c.h_scalars[1] != (k == 0 ? a : b - 1))
+        fail(BWT_HIP_EINTERNAL, "merge [%ld,%ld): the %s sample is at %u", (long)a, (long)b, k == 0 ? "first" : "last", c.h_scalars[1]);
+      (k == 0 ? out->s_rank : out->e_rank) = (i64)c.h_scalars[0];
+    }
     c.sync();  // the temporaries die here
-  }
-  g.sum_to_first(o_rank.get(), kept);
-  g.sum_to_first(o_pos.get(), kept);
-  if (k == 0) {
-    HIP_CHECK(hipMemcpyAsync(c.h_scalars, o_rank.get(), 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 1, o_rank.get() + (kept - 1), 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 2, o_pos.get() + (kept - 1), 4, hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    if ((i64)c.h_scalars[2] != b - 1)
-      fail(BWT_HIP_EINTERNAL, "merge [%ld,%ld): last sample is at %u, not at b-1", (long)a, (long)b, c.h_scalars[2]);
-    out->s_rank = (i64)c.h_scalars[0];
-    out->e_rank = (i64)c.h_scalars[1];
     out->samp_rank = std::move(o_rank);
     out->samp_pos = std::move(o_pos);
     out->n_samp = (i64)kept;
@@ -704,12 +661,11 @@ int bwt_hip_slice_info(const bwt_hip_slice *s_, int64_t *first, int64_t *size, i
   DIST_BEGIN
   if (!s_) fail(BWT_HIP_EINVAL, "invalid argument: slice");
   const Slice *s = reinterpret_cast<const Slice *>(s_);
-  const bool root = s->rank == 0;
   if (first) *first = s->first;
   if (size) *size = s->d->sizes[(size_t)s->rank];
-  if (s_rank) *s_rank = root ? s->d->s_rank : -1;
-  if (e_rank) *e_rank = root ? s->d->e_rank : -1;
-  if (n_samples) *n_samples = root ? s->d->n_samp : 0;
+  if (s_rank) *s_rank = s->rank == 0 ? s->d->s_rank : -1;
+  if (e_rank) *e_rank = s->rank == s->d->first + s->d->q - 1 ? s->d->e_rank : -1;
+  if (n_samples) *n_samples = s->d->n_samp;
   DIST_END
 }
 
@@ -737,7 +693,6 @@ int bwt_hip_slice_get_samples(bwt_hip_ctx *ctx, const bwt_hip_slice *s_, int64_t
   const Slice *s = reinterpret_cast<const Slice *>(s_);
   Ctx &c = ctx->c;
   HIP_CHECK(hipSetDevice(c.device));
-  if (s->rank != 0) fail(BWT_HIP_EINVAL, "the samples are on rank 0");
   const i64 k = s->d->n_samp < cap ? s->d->n_samp : cap;
   if (k > 0) {
     DBuf<i64> wr(c, (size_t)k), wp(c, (size_t)k);
@@ -768,9 +723,11 @@ int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host
   if (rc0 != 0) return rc0;
   std::vector<int> rcs((size_t)world, 0);
   std::vector<std::string> msgs((size_t)world);
+  std::vector<bwt_hip_ctx *> ctxs((size_t)world, nullptr);
+  std::vector<bwt_hip_slice *> slices((size_t)world, nullptr);
   auto body = [&](int k) {
-    bwt_hip_ctx *ctx = nullptr;
-    bwt_hip_slice *sl = nullptr;
+    bwt_hip_ctx *&ctx = ctxs[(size_t)k];
+    bwt_hip_slice *&sl = slices[(size_t)k];
     int rc = bwt_hip_create(devices[k], &ctx);
     if (rc == 0) rc = bwt_hip_set_text(ctx, T_host, n);
     // a rank that cannot start still has to meet the others: without its transfers they would wait for ever;
@@ -783,26 +740,41 @@ int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host
       e->hub->cv.notify_all();
     }
     if (rc == 0) {
-      int64_t first = 0, size = 0, sr = -1, er = -1, nsmp = 0;
-      rc = bwt_hip_slice_info(sl, &first, &size, &sr, &er, &nsmp);
+      int64_t first = 0;
+      rc = bwt_hip_slice_info(sl, &first, nullptr, nullptr, nullptr, nullptr);
       if (rc == 0) rc = bwt_hip_slice_get_L(ctx, sl, L_host + first);
-      if (rc == 0 && k == 0) {
-        if (s_rank) *s_rank = sr;
-        if (e_rank) *e_rank = er;
-        if (n_samples) *n_samples = nsmp;
-        if (samp_rank && samp_pos && samp_cap > 0) rc = bwt_hip_slice_get_samples(ctx, sl, samp_rank, samp_pos, samp_cap);
-      }
     }
     if (rc != 0) msgs[(size_t)k] = bwt_hip_last_error();
     rcs[(size_t)k] = rc;
-    bwt_hip_slice_free(sl);
-    bwt_hip_transport_free(tr[(size_t)k]);
-    if (ctx) bwt_hip_destroy(ctx);
   };
   std::vector<std::thread> th_;
   for (int k = 1; k < world; k++) th_.push_back(std::thread(body, k));
   body(0);
   for (auto &x : th_) x.join();
+  // every rank holds the samples of its own text range: they follow each other in the caller's arrays
+  bool ok = true;
+  for (int k = 0; k < world; k++) ok = ok && rcs[(size_t)k] == 0;
+  int64_t at = 0;
+  for (int k = 0; k < world && ok; k++) {
+    int64_t sr = -1, er = -1, nsmp = 0;
+    int rc = bwt_hip_slice_info(slices[(size_t)k], nullptr, nullptr, &sr, &er, &nsmp);
+    if (rc == 0 && k == 0 && s_rank) *s_rank = sr;
+    if (rc == 0 && k == world - 1 && e_rank) *e_rank = er;
+    if (rc == 0 && samp_rank && samp_pos && at < samp_cap)
+      rc = bwt_hip_slice_get_samples(ctxs[(size_t)k], slices[(size_t)k], samp_rank + at, samp_pos + at, samp_cap - at);
+    at += nsmp;
+    if (rc != 0) {
+      msgs[(size_t)k] = bwt_hip_last_error();
+      rcs[(size_t)k] = rc;
+      ok = false;
+    }
+  }
+  if (n_samples) *n_samples = at;
+  for (int k = 0; k < world; k++) {
+    bwt_hip_slice_free(slices[(size_t)k]);
+    bwt_hip_transport_free(tr[(size_t)k]);
+    if (ctxs[(size_t)k]) bwt_hip_destroy(ctxs[(size_t)k]);
+  }
   for (int k = 0; k < world; k++)
     if (rcs[(size_t)k] != 0) fail(rcs[(size_t)k], "rank %d: %s", k, msgs[(size_t)k].c_str());
   DIST_END

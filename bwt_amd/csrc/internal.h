@@ -380,7 +380,8 @@ Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
 
 // dist.hip: pieces of a merge spread over several GPUs
 void partition_bounds(u64 m, u32 parts, i64 *lo_out);
-void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host);
+// perm (may be null): perm[x] = index in `in` of the value that went to out[x]
+void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm = nullptr);
 // Symbols between GPUs as two bits each (texts whose symbols span at most four consecutive values): `count`
 // symbols at src (any alignment) -> wire_bytes(count) bytes at packed, and back to dst (any alignment).  The
 // unpacking kernel reads up to WIRE_PAD bytes past the packed stream: buffers that receive one are that much longer.
@@ -389,20 +390,27 @@ static inline size_t wire_bytes(u64 count) { return (size_t)((count + 3) / 4); }
 constexpr size_t WIRE_PAD = 8;
 void wire_pack2(Ctx &c, const u8 *src, u64 count, u8 *packed);
 void wire_unpack2(Ctx &c, const u8 *packed, u64 count, u8 *dst);
-struct ResamplePart {
-  const i64 *l_rank, *l_pos;
-  u64 nl;
-  const i64 *r_rank, *r_pos;
-  u64 nr;
-  i64 a, cc;           // first position of the left and of the right block
-  u64 A, B;            // ns_out - 1, nl + nr - 1
-  const u32 *S_local;  // S'[i - i_lo] for the left ranks i in [i_lo, i_hi): right suffixes of this part placed before i
-  u64 i_lo, i_hi, right_before;  // right_before: right suffixes in lower parts
-  const u32 *g_local;  // g_j for the positions j in [p_lo, p_hi), text order
-  u64 p_lo, p_hi;
-  i64 *o_rank, *o_pos;
+// Samples that stay with their holders (dist.hip): look-up requests grouped by the member that answers them.
+// left: queries[x] = left rank - first left rank of the answering part, perm[x] = the sample it belongs to;
+// right: queries[i] = pos[i] - first position of the answering member's chains (samples are in position order, so
+// the groups are too).  counts[d] = requests for member d.
+void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts);
+void samples_route_right(Ctx &c, const u32 *pos, u64 n, i64 cpos, u64 r, u32 members, u32 *queries, i64 *counts);
+// ans[x]: for the first n_left requests the new absolute rank of the left sample, for the n_right after them g
+void samples_answer(Ctx &c, const u32 *q, u64 n_left, u64 n_right, const u32 *S_local, u64 i_lo, u64 right_before, i64 a,
+                    const u32 *g_local, u32 *ans);
+struct SamplePlace {
+  const u32 *rank, *pos;  // the holder's samples (absolute ranks)
+  u64 n;
+  const u32 *ans, *perm;  // answers in request order; perm null: request x = sample x
+  u32 right_shift;        // 0 for a left holder; for a right holder c - a: new rank = rank - right_shift + g
+  u64 first_index;        // index of the holder's first sample in the merge's whole sequence (left by position, then right)
+  u64 first_slot;         // samples_taken_before(first_index)
+  u64 A, B;               // ns_out - 1, nl + nr - 1
+  u32 *o_rank, *o_pos;    // the holder's kept samples, in order
 };
-void resample_part(Ctx &c, const ResamplePart &R);
+void samples_place(Ctx &c, const SamplePlace &P);
+u64 samples_taken_before(u64 i, u64 A, u64 B);  // samples kept among the first i of the sequence (include/bwt.h:412, :436 in closed form)
 
 // api.hip: bwt_rec (leaf iff b-a <= th, else split at (a+b)/2 and merge); the calling thread's error message
 Block *build_rec(Ctx &c, i64 a, i64 b, i64 th, i64 ns, i64 seg);

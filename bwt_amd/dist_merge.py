@@ -1,17 +1,17 @@
 """One text, several GPUs, every merge spread over all GPUs of its subtree.
 
 bwt_amd.multi_gpu.pmbwt_tree leaves the upper levels of the merge tree to fewer and fewer GPUs.  Here a block of
-the tree that spans q GPUs stays distributed over them as q slices of its L (rank ranges), with the samples and the
-special ranks on the first of them, and a merge of two such blocks (reference include/bwt.h:791-847) runs on all 2q:
+the tree that spans q GPUs stays distributed over them as q slices of its L (rank ranges), each keeping the block's
+samples of its own text range, and a merge of two such blocks (reference include/bwt.h:791-847) runs on all 2q:
 
   1. the left block's L is sent to every GPU of the group (point-to-point, all links at once); each builds the left
      rank structure; 2. the right block's text positions are split evenly and every GPU runs the LF chains of its share
      (g_j = number of left suffixes below T[j:] depends on the left block and the text only, and the text is on every
      GPU); 3. the merge is cut by left rank into 2q parts (bwt_hip_dist_bounds): an all-to-all moves every g value to
      the GPU that owns its part, a second one the right symbols each part interleaves; 4. every GPU builds the prefix
-     sums of its part and writes its slice of the merged L; 5. the samples of both blocks go to every GPU, each
-     computes the new ranks it knows (left samples through its prefix sums, right samples through its chains) and a sum
-     to the group's first GPU completes the merged sample set.
+     sums of its part and writes its slice of the merged L; 5. the samples do not move: every GPU keeps those of its
+     own text range, asks the GPU that knows for the number each new rank needs (the part's prefix sums for a left
+     sample, g for a right one: two small all-to-alls) and thins its own by the reference's rule.
 
 Exchanged per merge and GPU: the left L in (m bytes, or m/4 when the text's symbols span at most four values and
 L crosses the links as two bits per symbol), about 4r/G bytes of g values and r/G (or r/4G) bytes of right symbols
@@ -29,7 +29,9 @@ from . import dist_bounds
 
 class DistBlock:
     """Block [a,b) spread over `ranks` (global ranks, ascending): slice i of L, `sizes[i]` symbols, is on ranks[i].
-    samples (rank, pos: int64 tensors) and s_rank / e_rank (block-relative + a) are valid on ranks[0] only."""
+    Every rank keeps the block's samples whose positions lie in the text range it built its own subtree on (rank =
+    block-relative rank + a, pos: 32-bit words held in int32 tensors, sorted by position; the ranks in order hold the
+    samples in order).  s_rank is known on ranks[0], e_rank on ranks[-1]."""
 
     def __init__(self, a, b, ranks, sizes, L, s_rank=-1, e_rank=-1, samp_rank=None, samp_pos=None):
         self.a, self.b, self.ranks, self.sizes, self.L = a, b, list(ranks), list(sizes), L
@@ -102,20 +104,6 @@ class Comm:
         for lo, hi, buf in stage:
             out[lo:hi].copy_(buf)
 
-    def broadcast(self, t, src_rank):
-        w = self._wire(t)
-        self.dist.broadcast(w, src=src_rank, group=self.group)
-        if self.host_staging:
-            t.copy_(w)
-        return t
-
-    def sum_to(self, t, dst_rank):
-        w = self._wire(t)
-        self.dist.reduce(w, dst=dst_rank, op=self.dist.ReduceOp.SUM, group=self.group)
-        if self.host_staging and self.me == dst_rank:
-            t.copy_(w)
-        return t
-
 
 class HipDistOps:
     """The per-GPU steps through the C-ABI; tensors are torch tensors on this process's GPU."""
@@ -141,7 +129,7 @@ class HipDistOps:
         self._ready()
         blk.export_device(L.data_ptr(), r.data_ptr(), p.data_ptr())
         self.ctx.sync()
-        d = DistBlock(a, b, [me], [b - a], L, blk.s_rank, blk.e_rank, r, p)
+        d = DistBlock(a, b, [me], [b - a], L, blk.s_rank, blk.e_rank, r.to(self.torch.int32), p.to(self.torch.int32))
         blk.free()
         return d
 
@@ -187,14 +175,29 @@ class HipDistOps:
         self.ctx.dist_merge_slice(lL.data_ptr(), mL, rL.data_ptr(), rn, g_rel.data_ptr(), out.data_ptr(), S.data_ptr())
         return out, S
 
-    def resample(self, l_rank, l_pos, r_rank, r_pos, a, c, ns_out, S, i_lo, i_hi, right_before, g, p_lo, p_hi):
-        nl, nr = int(l_rank.numel()), int(r_rank.numel())
-        kept = self.ctx.dist_resample(0, 0, nl, 0, 0, nr, a, c, ns_out, 0, 0, 0, 0, 0, 0, 0, 0, 0)
-        o_rank, o_pos = self.zeros(kept, self.torch.int64), self.zeros(kept, self.torch.int64)
+    def samples_route(self, is_left, rank, pos, a, c, m, r, members):
+        n = int(pos.numel())
+        queries = self.empty(n, self.torch.int32)
+        perm = self.empty(n if is_left else 0, self.torch.int32)
         self._ready()
-        self.ctx.dist_resample(l_rank.data_ptr(), l_pos.data_ptr(), nl, r_rank.data_ptr(), r_pos.data_ptr(), nr, a, c, ns_out,
-                               S.data_ptr(), i_lo, i_hi, right_before, g.data_ptr(), p_lo, p_hi, o_rank.data_ptr(),
-                               o_pos.data_ptr())
+        counts = self.ctx.dist_samples_route(is_left, rank.data_ptr(), pos.data_ptr(), n, a, c, m, r, members,
+                                             queries.data_ptr(), perm.data_ptr())
+        return queries, perm, [int(x) for x in counts]
+
+    def samples_answer(self, queries, n_left, n_right, S, i_lo, right_before, a, g):
+        out = self.empty(n_left + n_right, self.torch.int32)
+        self._ready()
+        self.ctx.dist_samples_answer(queries.data_ptr(), n_left, n_right, S.data_ptr(), i_lo, right_before, a, g.data_ptr(),
+                                     out.data_ptr())
+        return out
+
+    def samples_place(self, is_left, rank, pos, answers, perm, a, c, first_index, n_all, ns_out):
+        n = int(pos.numel())
+        kept = self.ctx.dist_samples_place(is_left, 0, 0, n, 0, 0, a, c, first_index, n_all, ns_out, 0, 0)
+        o_rank, o_pos = self.empty(kept, self.torch.int32), self.empty(kept, self.torch.int32)
+        self._ready()
+        self.ctx.dist_samples_place(is_left, rank.data_ptr(), pos.data_ptr(), n, answers.data_ptr(), perm.data_ptr(), a, c,
+                                    first_index, n_all, ns_out, o_rank.data_ptr(), o_pos.data_ptr())
         return o_rank, o_pos
 
     def free_block(self, lb):
@@ -230,7 +233,7 @@ def dist_merge(ops, comm, blk, ns_req):
     rsizes = [meta[q + j][5] for j in range(q)]
     if sum(lsizes) != m or sum(rsizes) != r:
         raise RuntimeError("slice sizes do not add up to the blocks")
-    s_rank_l, e_rank_l, nl, nr = meta[0][2], meta[0][3], meta[0][4], meta[q][4]
+    s_rank_l, e_rank_l = meta[0][2], meta[q - 1][3]
 
     # 1. the left block's L on every GPU of the group
     loff = [0]
@@ -309,33 +312,32 @@ def dist_merge(ops, comm, blk, ns_req):
     out, S = ops.merge_slice(fullL[i_lo:i_hi], rL, g_in)
     sizes = [min(lo[d + 1], m) - min(lo[d], m) + R[d] for d in range(G)]
 
-    # 5. samples: everybody learns both sample sets, places what it can, the first GPU adds up.  Ranks and positions
-    # are below 2^32, so they travel as 32-bit words (bit patterns in int32 tensors; adding zeros cannot carry).
-    def narrow(t):
-        return t.to(torch.int32)
-
-    def widen(t):
-        return t.to(torch.int64) & 0xFFFFFFFF
-
-    wire = []
-    for owner, cnt, src in ((root, nl, blk.samp_rank), (root, nl, blk.samp_pos), (rroot, nr, blk.samp_rank), (rroot, nr, blk.samp_pos)):
-        t = narrow(src) if me == owner else ops.empty(cnt, torch.int32)
-        comm.broadcast(t, owner)
-        wire.append(widen(t))
-    l_rank, l_pos, r_rank, r_pos = wire
+    # 5. the samples stay with their holders: requests out, answers back, every holder thins its own
+    held = [meta[j][4] for j in range(G)]
+    n_all, first_index = sum(held), sum(held[:k])
     ns_out = min(ns_req, m + r)
-    o_rank, o_pos = ops.resample(l_rank, l_pos, r_rank, r_pos, a, c, ns_out, S, i_lo, i_hi, rb[k], g, p_lo, p_hi)
-    o_rank, o_pos = narrow(o_rank), narrow(o_pos)
-    comm.sum_to(o_rank, root)
-    comm.sum_to(o_pos, root)
-    o_rank, o_pos = widen(o_rank), widen(o_pos)
-    new = DistBlock(a, b, ranks, sizes, out)
-    if me == root:
-        first = [int(x) for x in o_rank[:1].cpu().tolist()] + [int(x) for x in o_rank[-1:].cpu().tolist()]
-        last_pos = int(o_pos[-1:].cpu().tolist()[0])
-        if last_pos != b - 1:
-            raise RuntimeError("merge [%d,%d): last sample is at %d, not at b-1" % (a, b, last_pos))
-        new.s_rank, new.e_rank, new.samp_rank, new.samp_pos = first[0], first[1], o_rank, o_pos
+    queries, perm, ask = ops.samples_route(k < q, blk.samp_rank, blk.samp_pos, a, c, m, r, G)
+    asked = comm.all_gather_i64(ask)  # asked[src][member]
+    incoming = [asked[j][k] for j in range(G)]
+    q_in = comm.all_to_all(queries, ask, incoming)
+    answers = ops.samples_answer(q_in, sum(incoming[:q]), sum(incoming[q:]), S, i_lo, rb[k], a, g)
+    a_in = comm.all_to_all(answers, incoming, ask)
+    o_rank, o_pos = ops.samples_place(k < q, blk.samp_rank, blk.samp_pos, a_in, perm, a, c, first_index, n_all, ns_out)
+    new = DistBlock(a, b, ranks, sizes, out, samp_rank=o_rank, samp_pos=o_pos)
+
+    def word(t, i):  # element i of an int32 tensor that holds unsigned 32-bit values
+        return int(t[i:i + 1].cpu().tolist()[0]) & 0xFFFFFFFF
+
+    # the block's first sample is at position a (the first holder's first), its last at b - 1 (the last holder's last)
+    if k == 0:
+        if word(o_pos, 0) != a:
+            raise RuntimeError("merge [%d,%d): first sample is at %d, not at a" % (a, b, word(o_pos, 0)))
+        new.s_rank = word(o_rank, 0)
+    if k == G - 1:
+        last = int(o_pos.numel()) - 1
+        if word(o_pos, last) != b - 1:
+            raise RuntimeError("merge [%d,%d): last sample is at %d, not at b-1" % (a, b, word(o_pos, last)))
+        new.e_rank = word(o_rank, last)
     return new
 
 
@@ -367,9 +369,6 @@ def warm_groups(dist, groups, rank, world, device, host_staging):
         comm.spread([mine if r == rank else None for r in comm.ranks], out, list(range(G + 1)))
         if [int(x) for x in out.cpu().tolist()] != list(range(1, G + 1)):
             raise RuntimeError("point-to-point warm-up returned %r on rank %d" % (out.cpu().tolist(), rank))
-        t = torch.ones(1, dtype=torch.int32, device=dev)
-        comm.broadcast(t, comm.ranks[0])
-        comm.sum_to(t, comm.ranks[0])
         G *= 2
     if not host_staging and getattr(device, "type", str(device)) == "cuda":
         torch.cuda.synchronize(device)
@@ -406,4 +405,28 @@ def gather_L(blk, rank, world, dist, device, host_staging):
             parts.append(buf)
         return np.concatenate([p.cpu().numpy() for p in parts])
     dist.send(mine.contiguous(), 0)
+    return None
+
+
+def gather_samples(blk, rank, world, dist, device, host_staging):
+    """The final block's samples (ranks, positions: int64 numpy arrays) and its (s_rank, e_rank) on rank 0 (tests; the
+    benchmark leaves them where they are)."""
+    import torch
+    wire_dev = "cpu" if host_staging else device
+    counts = torch.zeros(world, dtype=torch.int64, device=wire_dev)
+    counts[rank] = blk.n_samples
+    dist.all_reduce(counts)
+    counts = [int(x) for x in counts.cpu().tolist()]
+    ends = torch.tensor([blk.e_rank if rank == world - 1 else 0], dtype=torch.int64, device=wire_dev)
+    dist.all_reduce(ends)
+    mine = torch.stack([blk.samp_rank, blk.samp_pos]).to(wire_dev).contiguous()
+    if rank == 0:
+        parts = [mine]
+        for src in range(1, world):
+            buf = torch.empty((2, counts[src]), dtype=torch.int32, device=wire_dev)
+            dist.recv(buf, src)
+            parts.append(buf)
+        both = np.concatenate([p.cpu().numpy() for p in parts], axis=1).view(np.uint32).astype(np.int64)
+        return both[0], both[1], blk.s_rank, int(ends.item())
+    dist.send(mine, 0)
     return None

@@ -232,7 +232,7 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
             "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
-                                    "subtree (RCCL point-to-point + all-to-all); L stays sliced over the GPUs, samples on rank 0"
+                                    "subtree (RCCL point-to-point + all-to-all); L stays sliced over the GPUs, every GPU keeps the samples of its own text range"
                                     if algo in ("dist", "native") else
                                     "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0")
                                    % (n, total_leaves, world),

@@ -232,17 +232,32 @@ int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL
 #define BWT_HIP_NOALLOC_MAX_RIGHT 4194304
 int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev,
                                      int64_t rn, uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev);
-/* This part's share of the merged block's samples.  Inputs: all samples of the left block [a,c) and of the
-   right block [c,b) (rank = block-relative rank + first position, sorted by position); S_dev of this part
-   with its left ranks [i_lo, i_hi) and the number of right suffixes in lower parts; g_dev (text order) for
-   the positions [p_lo, p_hi) whose chains this GPU ran.  Kept samples this GPU can place are written to
-   their slot of o_rank_dev / o_pos_dev (*kept entries; zero them first and add the arrays of all GPUs up).
-   With null output arrays only *kept is computed. */
-int bwt_hip_dist_resample(bwt_hip_ctx *ctx, const int64_t *l_rank_dev, const int64_t *l_pos_dev, int64_t nl,
-                          const int64_t *r_rank_dev, const int64_t *r_pos_dev, int64_t nr, int64_t a, int64_t c,
-                          int64_t ssa_n_samples_out, const uint32_t *S_dev, int64_t i_lo, int64_t i_hi,
-                          int64_t right_before, const uint32_t *g_dev, int64_t p_lo, int64_t p_hi,
-                          int64_t *o_rank_dev, int64_t *o_pos_dev, int64_t *kept);
+/* The merged block's samples (resample_sa, include/bwt.h:366-453), with the samples left where they are: every
+   process keeps the samples of a block whose positions lie in the text range it built its own subtree on (sorted
+   by position; the processes in order hold the block's samples in order; ranks are block-relative + the block's
+   first position, 32-bit words).  In a merge of [a,c) and [c,b) over `members` processes a holder asks, per sample,
+   the process that knows the number its new rank needs:
+   route   is_left: queries_dev[x] = left rank - first left rank of the part that owns it, grouped by part, and
+           perm_dev[x] = the sample the request belongs to; otherwise queries_dev[i] = pos[i] - first position of the
+           member whose chains cover pos[i] (member d covers [c + d*r/members, c + (d+1)*r/members)), which are grouped
+           already.  counts[d] = requests for member d.
+   answer  the requests a process received, those of left holders first (n_left), then those of right holders
+           (n_right): answers_dev[x] = new rank of the left sample (from the part's S_dev, its first left rank i_lo and
+           the right suffixes in lower parts) resp. g of the right sample (g_dev: text order, from the first position
+           of this process's chains).
+   place   the holder's answers, in request order, become its share of the merged samples: sample i of the holder
+           has index first_index + i among the n_all samples of both blocks; the kept ones (the reference's thinning
+           to ssa_n_samples_out) go to o_rank_dev / o_pos_dev in order, *kept of them.  With null outputs only *kept. */
+int bwt_hip_dist_samples_route(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
+                               int64_t a, int64_t c, int64_t m, int64_t r, int members, uint32_t *queries_dev,
+                               uint32_t *perm_dev, int64_t *counts);
+int bwt_hip_dist_samples_answer(bwt_hip_ctx *ctx, const uint32_t *queries_dev, int64_t n_left, int64_t n_right,
+                                const uint32_t *S_dev, int64_t i_lo, int64_t right_before, int64_t a, const uint32_t *g_dev,
+                                uint32_t *answers_dev);
+int bwt_hip_dist_samples_place(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
+                               const uint32_t *answers_dev, const uint32_t *perm_dev, int64_t a, int64_t c,
+                               int64_t first_index, int64_t n_all, int64_t ssa_n_samples_out, uint32_t *o_rank_dev,
+                               uint32_t *o_pos_dev, int64_t *kept);
 
 /* ---- the whole build over several GPUs -------------------------------------------------------------- */
 /* The reference builds in one address space.  Here the recursion tree of bwt::bwt_rec (include/bwt.h:854-865) is cut
@@ -279,15 +294,17 @@ int bwt_hip_transport_rccl(bwt_hip_ctx *ctx, const uint8_t id[128], int rank, in
 int bwt_hip_transport_local(int world, bwt_hip_transport **out);
 void bwt_hip_transport_free(bwt_hip_transport *t);
 
-/* This rank's share of a block that is spread over the ranks: slice `rank` of L (by rank range), the samples and
-   special ranks on rank 0 only. */
+/* This rank's share of a block that is spread over the ranks: slice `rank` of L (by rank range) and the block's
+   samples whose positions lie in the text range this rank built its own subtree on (ranks in order hold the
+   samples in position order).  s_rank is known to rank 0, e_rank to the last rank. */
 typedef struct bwt_hip_slice bwt_hip_slice;
 /* bwt::pmbwt (include/bwt.h:867-883) over t->world ranks (a power of two); called by every rank with its own
    context, all of which hold the same text.  The tree is the reference's for this bwt_rec_threshold; it must have
    at least `world` leaves at depth log2(world) (BWT_HIP_EINVAL otherwise). */
 int bwt_hip_dist_pmbwt(bwt_hip_ctx *ctx, bwt_hip_transport *t, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
                        int64_t build_gap_segment_sz, bwt_hip_slice **out);
-/* first: rank of the slice's first symbol; the other outputs as bwt_hip_block_info (valid on rank 0, -1 elsewhere). */
+/* first: rank of the slice's first symbol; s_rank / e_rank as bwt_hip_block_info, -1 on the ranks that do not
+   know them; n_samples: samples this rank holds.  Any output pointer may be null. */
 int bwt_hip_slice_info(const bwt_hip_slice *s, int64_t *first, int64_t *size, int64_t *s_rank, int64_t *e_rank,
                        int64_t *n_samples);
 int bwt_hip_slice_L_device(const bwt_hip_slice *s, const uint8_t **L_dev);
@@ -297,7 +314,8 @@ void bwt_hip_slice_free(bwt_hip_slice *s);
 
 /* The same in one call for a host program that owns several GPUs: one thread and one context per entry of
    `devices` (a device may be listed more than once: its ranks then share it), the text uploaded to each, slices
-   gathered into L_host[0:n).  Sample outputs as bwt_hip_block_get_samples; *n_samples receives their number.
+   and samples gathered into L_host[0:n) and the sample arrays.  Sample outputs as bwt_hip_block_get_samples;
+   *n_samples receives their number.
    n_devices = 1 is the plain single-GPU build.  If the tree has fewer than n_devices leaves at that depth, the
    largest power of two of GPUs that it feeds is used; *used (may be null) says how many. */
 int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t bwt_rec_threshold,

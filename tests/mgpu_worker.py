@@ -78,7 +78,14 @@ class NumpyDistOps:
         r, p = blk.samples()
         t = self.torch
         return DistBlock(a, b, [me], [b - a], t.from_numpy(self.base.L[a:b].copy()), blk.s_rank, blk.e_rank,
-                         t.from_numpy(r), t.from_numpy(p))
+                         self._words(r), self._words(p))
+
+    def _words(self, v):  # unsigned 32-bit values in an int32 tensor, as the device path holds them
+        return self.torch.from_numpy(np.asarray(v).astype(np.uint32).view(np.int32).copy())
+
+    @staticmethod
+    def _ints(t):
+        return t.numpy().view(np.uint32).astype(np.int64)
 
     def left_block(self, a, c, L, s_rank, e_rank):
         return (a, c)
@@ -138,10 +145,31 @@ class NumpyDistOps:
         out[~is_left] = rL.numpy()
         return self.torch.from_numpy(out), self.torch.from_numpy(S.astype(np.uint32).view(np.int32).copy())
 
-    def resample(self, l_rank, l_pos, r_rank, r_pos, a, c, ns_out, S, i_lo, i_hi, right_before, g, p_lo, p_hi):
-        nl, nr = int(l_rank.numel()), int(r_rank.numel())
-        nn = nl + nr
-        A, B = ns_out - 1, nn - 1
+    # the three sample steps as include/bwt_hip.h defines them (bwt_hip_dist_samples_route / _answer / _place)
+    def samples_route(self, is_left, rank, pos, a, c, m, r, members):
+        if is_left:
+            lo, scale = self.bounds(m, members)
+            rk = self._ints(rank) - a
+            part = ((rk.astype(np.uint64) * np.uint64(scale)) >> np.uint64(32)).astype(np.int64)
+            order = np.argsort(part, kind="stable")[::-1].copy()   # any order inside a part is allowed: a reversed one
+            order = order[np.argsort(part[order], kind="stable")]
+            queries = rk[order] - np.array(lo, dtype=np.int64)[part[order]]
+            return self._words(queries), self._words(order), [int(x) for x in np.bincount(part, minlength=members)]
+        p = self._ints(pos)
+        bound = np.array([c + d * r // members for d in range(members + 1)], dtype=np.int64)
+        first = np.searchsorted(p, bound, side="left")
+        assert first[0] == 0 and first[-1] == len(p)
+        member = np.searchsorted(first[1:], np.arange(len(p)), side="right")
+        return self._words(p - bound[member]), self._words([]), [int(x) for x in np.diff(first)]
+
+    def samples_answer(self, queries, n_left, n_right, S, i_lo, right_before, a, g):
+        qv, Sn, gn = self._ints(queries), self._ints(S), self._ints(g)
+        left = a + i_lo + right_before + qv[:n_left] + Sn[qv[:n_left]]
+        right = gn[qv[n_left:n_left + n_right]]
+        return self._words(np.concatenate([left, right]))
+
+    def samples_place(self, is_left, rank, pos, answers, perm, a, c, first_index, n_all, ns_out):
+        A, B = ns_out - 1, n_all - 1
 
         def taken(i):  # include/bwt.h:412, :436 in closed form
             if i == 0:
@@ -149,23 +177,18 @@ class NumpyDistOps:
             if B == 0:
                 return 1
             return min(i, 1 + ((i - 1) * A) // B)
-        kept = min(nn, 1 + ((nn - 1) * A) // B if B else 1) if nn else 0
+        rk, ps, ans = self._ints(rank), self._ints(pos), self._ints(answers)
+        owner = self._ints(perm) if is_left else np.arange(len(ps))
+        base = taken(first_index)
+        kept = taken(first_index + len(ps)) - base
         o_rank, o_pos = np.zeros(kept, dtype=np.int64), np.zeros(kept, dtype=np.int64)
-        Sn = S.numpy().view(np.uint32).astype(np.int64)
-        gn = g.numpy().view(np.uint32).astype(np.int64)
-        for i in range(nn):
-            t0, t1 = taken(i), taken(i + 1)
-            if t1 == t0:
-                continue
-            if i < nl:
-                rk = int(l_rank[i]) - a
-                if i_lo <= rk < i_hi:
-                    o_rank[t0], o_pos[t0] = a + rk + right_before + Sn[rk - i_lo], int(l_pos[i])
-            else:
-                p = int(r_pos[i - nl])
-                if p_lo <= p < p_hi:
-                    o_rank[t0], o_pos[t0] = a + int(r_rank[i - nl]) - c + gn[p - p_lo], p
-        return self.torch.from_numpy(o_rank), self.torch.from_numpy(o_pos)
+        for x in range(len(ps)):
+            i = int(owner[x])
+            t0, t1 = taken(first_index + i), taken(first_index + i + 1)
+            if t1 != t0:
+                o_rank[t0 - base] = ans[x] if is_left else rk[i] - (c - a) + ans[x]
+                o_pos[t0 - base] = ps[i]
+        return self._words(o_rank), self._words(o_pos)
 
 
 def export_import_check():
@@ -238,9 +261,9 @@ def main():
         dist_merge.warm_groups(dist, groups, rank, world, dev, staging)
         blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, staging)
         L = dist_merge.gather_L(blk, rank, world, dist, dev, staging)
+        samples = dist_merge.gather_samples(blk, rank, world, dist, dev, staging)
         if rank == 0:
-            np.savez(args.out, L=L, rank=blk.samp_rank.cpu().numpy(), pos=blk.samp_pos.cpu().numpy(), s_rank=blk.s_rank,
-                     e_rank=blk.e_rank, sizes=np.array(blk.sizes))
+            np.savez(args.out, L=L, rank=samples[0], pos=samples[1], s_rank=samples[2], e_rank=samples[3], sizes=np.array(blk.sizes))
         dist.barrier()
         dist.destroy_process_group()
         return

@@ -62,11 +62,18 @@ def main():
     rL = torch.randint(1, 5, (g_in.numel(),), dtype=torch.uint8, device=dev)
     out, S = timed("prefix sums + merge of the slice (mL=%d, rn=%d)" % (i_hi - i_lo, g_in.numel()),
                    lambda: ops.merge_slice(left.L[i_lo:i_hi], rL, g_in))
+    # this GPU's own samples (an eighth of the left block's, as a left holder): requests, answers, thinning
     nl = left.n_samples
-    r_rank = torch.arange(c, c + nl, dtype=torch.int64, device=dev)
-    r_pos = torch.linspace(c, b - 1, nl, device=dev, dtype=torch.float64).to(torch.int64)
-    timed("resample share (%d + %d samples)" % (nl, nl),
-          lambda: ops.resample(left.samp_rank, left.samp_pos, r_rank, r_pos, a, c, ns, S, i_lo, i_hi, 0, g, p_lo, p_hi))
+    share = slice(k * nl // G, (k + 1) * nl // G)
+    rank, pos = left.samp_rank[share].contiguous(), left.samp_pos[share].contiguous()
+
+    def sample_steps():
+        queries, perm, ask = ops.samples_route(True, rank, pos, a, c, m, r, G)
+        mine_q = queries[sum(ask[:k]):sum(ask[:k + 1])]  # the requests that stay on this GPU, answered G times over
+        q_in = mine_q.repeat(G)
+        ans = ops.samples_answer(q_in, int(q_in.numel()), 0, S, i_lo, 0, a, g)
+        return ops.samples_place(True, rank, pos, queries, perm, a, c, share.start, 2 * nl, ns)
+    timed("samples: route + answer + place (%d of %d + %d)" % (rank.numel(), nl, nl), sample_steps)
     mem = ctx.mem_stats()
     print("  library device memory peak %.1f GB; torch %.1f GB" % (mem["peak"] / 1e9, torch.cuda.max_memory_allocated() / 1e9))
 
