@@ -232,3 +232,25 @@ def test_config4_repetitive_4_6e8(ctx):
     assert h8(b4.L) == fnv
     b4.free()
     ctx.trim()
+
+
+def test_config3_n3_1e9_eight_ranks_share_the_gpu(ctx):
+    """Config 3's schedule at full size: bwt_hip_pmbwt_multi cuts 3.1e9 symbols over 8 ranks (here threads that share
+    the one GPU: the partition of every merge, the two-bit transfers of L between ranks, slices at odd offsets and the
+    samples that stay with their ranks are those of an 8-GPU run; only the copies stay on one device).  L, the special
+    ranks and the samples equal the single-context build of the same 8-leaf tree."""
+    import bwt_amd
+    n, ns = 3100000000, 19375000
+    th = -(-n // 8)
+    ctx.gen_text(n, 42, 4)
+    one = ctx.pmbwt(th, ns)
+    f1, info1 = h8(one.L), (one.s_rank, one.e_rank)
+    r1, p1 = one.samples()
+    one.free()
+    T = ctx.get_text()
+    ctx.trim()
+    L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * 8, T, th, ns)
+    del T
+    assert used == 8 and (s_rank, e_rank) == info1
+    assert h8(L) == f1
+    assert len(r) == len(r1) and (r == r1).all() and (p == p1).all()
