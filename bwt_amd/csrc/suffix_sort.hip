@@ -708,8 +708,10 @@ struct LeafEmit : EmitParams {
   // window, from wherever they are at hand.
   // (One thread per group, which reads each member's text once instead of once per comparison, is slower:
   // the pass waits on the latency of these reads, not on their number.)
+  // lds_L (with the leaf rank of its first byte): where L[r] goes instead of memory, for a caller that stores its
+  // stretch of L itself afterwards
   template <class Window>
-  __device__ __forceinline__ void direct_tied(const Window &w, u64 i, u32 slack_before) const {
+  __device__ __forceinline__ void direct_tied(const Window &w, u64 i, u32 slack_before, u8 *lds_L = nullptr, u64 lds_first = 0) const {
     if (*reinterpret_cast<volatile u32 *>(fail)) return;  // someone gave up already
     const u64 kfull = w.key(i);
     const u64 k = kfull & sym_mask;
@@ -740,7 +742,16 @@ struct LeafEmit : EmitParams {
       slack_smaller += (less && sl);
     }
     if (pos >= leaf_end) return;
-    place(gs + smaller - (slack_before - slack_ahead + slack_smaller), pos, (u32)kfull & 0xFFu);
+    const u64 r = gs + smaller - (slack_before - slack_ahead + slack_smaller);
+    if (lds_L) {
+      if (sa_out) sa_out[r] = pos;
+      if (L) {
+        lds_L[r - lds_first] = (u8)kfull;
+        note(r, pos);
+      }
+    } else {
+      place(r, pos, (u32)kfull & 0xFFu);
+    }
   }
 
   // window rank i holds leaf rank r
@@ -1036,9 +1047,17 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   __shared__ u64 tied_mask[BK_MASKS], slack_mask[SLACK ? BK_MASKS : 1];
   __shared__ u32 tied_pre[BK_MASKS + 1], slack_pre[SLACK ? BK_MASKS : 1];
   __shared__ u32 scan_s[4];
+  // The bucket's stretch of L is collected here and leaves as aligned 16-byte stores (one byte per lane, and none
+  // for the tied suffixes in between, left memory with partly written sectors: twice the bytes on the way out).
+  // Byte j of the stretch lies at lsym[lead + j], lead = its address modulo 16, so that aligned groups of the array
+  // are aligned groups of memory.  Not with window slack (ranks are then not index + constant) and not where the
+  // array would cost the second workgroup per CU its LDS (nine elements per thread; eight plus side bytes).
+  constexpr bool STAGE_L = !SLACK && ITEMS + (WIDE ? 1 : 0) <= 8;
+  __shared__ __align__(16) u8 lsym[STAGE_L ? ITEMS * BK_THREADS + 16 : 16];
   static_assert(BK_MASKS <= 256, "the flag words are scanned by the first four waves");
   const u32 s = start[blockIdx.x], cnt = start[blockIdx.x + 1] - s;  // cnt <= ITEMS * BK_THREADS: the caller has checked
   if (cnt == 0) return;
+  const u32 lead = STAGE_L ? (u32)(reinterpret_cast<uintptr_t>(E.L + s) & 15) : 0u;
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 wbase = w * (64 * ITEMS);
   const u64 *mine = E.v.e + s;
@@ -1165,7 +1184,16 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
       const u64 me = buf[idx];
       u32 sb = below;
       if (SLACK) sb += slack_pre[r * BK_WAVES + w] + (u32)__popcll(slack_mask[r * BK_WAVES + w] & lanemask_lt());
-      if (E.place_fast((u64)s + idx - sb, E.v.elem_pos(me), E.v.elem_prev(me, WIDE ? sbuf[idx] : 0u))) look |= 1u << r;
+      if constexpr (STAGE_L) {
+        const u32 pos = E.v.elem_pos(me);
+        if (E.sa_out) E.sa_out[(u64)s + idx] = pos;
+        if (E.L) {
+          lsym[lead + idx] = (u8)E.v.elem_prev(me, WIDE ? sbuf[idx] : 0u);
+          if (E.note_fast((u64)s + idx, pos)) look |= 1u << r;
+        }
+      } else {
+        if (E.place_fast((u64)s + idx - sb, E.v.elem_pos(me), E.v.elem_prev(me, WIDE ? sbuf[idx] : 0u))) look |= 1u << r;
+      }
     }
   }
   while (look) {  // usually one pass per wave instead of one per round
@@ -1190,7 +1218,23 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     const u32 idx = lo * 64 + select_bit(tied_mask[lo], t - tied_pre[lo]);
     u32 sb = below;
     if (SLACK) sb += slack_pre[idx >> 6] + (u32)__popcll(slack_mask[idx >> 6] & ((1ull << (idx & 63)) - 1ull));
-    E.direct_tied(win, (u64)s + idx, sb);
+    if constexpr (STAGE_L) E.direct_tied(win, (u64)s + idx, sb, lsym + lead, (u64)s);
+    else E.direct_tied(win, (u64)s + idx, sb);
+  }
+  if constexpr (STAGE_L) {
+    if (!E.L) return;
+    lds_barrier();
+    u8 *g0 = E.L + s - lead;  // 16-byte aligned
+    const u32 end = lead + cnt;
+    for (u32 t = tid; t * 16 < end; t += BK_THREADS) {
+      const u32 o = t * 16;
+      if (o >= lead && o + 16 <= end) {
+        *reinterpret_cast<uint4 *>(g0 + o) = *reinterpret_cast<const uint4 *>(lsym + o);
+      } else {
+        const u32 lo = o < lead ? lead : o, hi = o + 16 < end ? o + 16 : end;
+        for (u32 j = lo; j < hi; j++) g0[j] = lsym[j];
+      }
+    }
   }
 }
 
