@@ -1,7 +1,8 @@
 // Pieces of a merge that is spread over several GPUs (one process per GPU; the
 // exchange between them is done by the caller).  A merge of a left block of m
 // suffixes and a right block of r suffixes is cut into G parts by LEFT RANK: with
-//   part(v) = (v * scale) >> 32,   scale = floor(2^32 * G / (m + 1)),
+//   part(v) = ((v >> shift) * scale) >> 32,   scale = floor(2^32 * G / ((m >> shift) + 1)),
+// (shift = 0, or 13 where the g values travel grouped by gap bucket: parts then begin at multiples of 8192)
 // part k owns the left ranks i with part(i) == k and the right suffixes j whose
 // g_j (number of smaller left suffixes) has part(g_j) == k.  Those right suffixes
 // are consecutive in the right block's order, and part k's output -- its left
@@ -18,10 +19,10 @@ constexpr int PT_THREADS = 256;
 constexpr int PT_ITEMS = 16;
 constexpr int PT_MAX_PARTS = 256;
 
-__device__ __forceinline__ u32 part_of(u32 v, u64 scale) { return (u32)(((u64)v * scale) >> 32); }
+__device__ __forceinline__ u32 part_of(u32 v, u64 scale, int shift) { return (u32)(((u64)(v >> shift) * scale) >> 32); }
 
 __global__ void __launch_bounds__(PT_THREADS)
-    k_part_count(const u32 *__restrict__ in, u64 count, u64 scale, u32 parts, unsigned long long *__restrict__ counts) {
+    k_part_count(const u32 *__restrict__ in, u64 count, u64 scale, int shift, u32 parts, unsigned long long *__restrict__ counts) {
   __shared__ u32 cnt[PT_MAX_PARTS];
   const u32 tid = threadIdx.x;
   cnt[tid] = 0;
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(PT_THREADS)
 #pragma unroll 4
   for (int k = 0; k < PT_ITEMS; k++) {
     u64 i = base + (u64)k * PT_THREADS + tid;
-    if (i < count) atomicAdd(&cnt[part_of(in[i], scale)], 1u);
+    if (i < count) atomicAdd(&cnt[part_of(in[i], scale, shift)], 1u);
   }
   __syncthreads();
   if (tid < parts && cnt[tid]) atomicAdd(&counts[tid], (unsigned long long)cnt[tid]);
@@ -39,7 +40,7 @@ __global__ void __launch_bounds__(PT_THREADS)
 // out: the values grouped by part (order inside a part is arbitrary), each minus the first left rank of
 // its part.  cursors[k] starts as the first output index of part k.
 __global__ void __launch_bounds__(PT_THREADS)
-    k_part_scatter(const u32 *__restrict__ in, u64 count, u64 scale, u32 parts, const u32 *__restrict__ part_lo,
+    k_part_scatter(const u32 *__restrict__ in, u64 count, u64 scale, int shift, u32 parts, const u32 *__restrict__ part_lo,
                    unsigned long long *__restrict__ cursors, u32 *__restrict__ out, u32 *__restrict__ perm) {
   __shared__ u32 cnt[PT_MAX_PARTS];
   __shared__ unsigned long long start[PT_MAX_PARTS];
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(PT_THREADS)
   for (int k = 0; k < PT_ITEMS; k++) {
     u64 i = base + (u64)k * PT_THREADS + tid;
     v[k] = i < count ? in[i] : 0u;
-    if (i < count) slot[k] = atomicAdd(&cnt[part_of(v[k], scale)], 1u);
+    if (i < count) slot[k] = atomicAdd(&cnt[part_of(v[k], scale, shift)], 1u);
   }
   __syncthreads();
   if (tid < parts && cnt[tid]) start[tid] = atomicAdd(&cursors[tid], (unsigned long long)cnt[tid]);
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(PT_THREADS)
   for (int k = 0; k < PT_ITEMS; k++) {
     u64 i = base + (u64)k * PT_THREADS + tid;
     if (i < count) {
-      u32 p = part_of(v[k], scale);
+      u32 p = part_of(v[k], scale, shift);
       out[start[p] + slot[k]] = v[k] - part_lo[p];
       if (perm) perm[start[p] + slot[k]] = (u32)i;  // where the value came from
     }
@@ -71,20 +72,20 @@ __global__ void __launch_bounds__(PT_THREADS)
 // first value v with part(v) >= k
 static u64 part_lower_bound(u64 k, u64 scale) { return ((k << 32) + scale - 1) / scale; }
 
-void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm) {
+void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm, int shift) {
   if (parts < 1 || parts > PT_MAX_PARTS) fail(BWT_HIP_EINVAL, "partition: 1..%d parts", PT_MAX_PARTS);
-  const u64 scale = (((u64)parts) << 32) / (m + 1);
+  const u64 scale = (((u64)parts) << 32) / ((m >> shift) + 1);
   DBuf<unsigned long long> d(c, 2 * (size_t)parts);
   DBuf<u32> lo(c, parts);
   u32 h_lo[PT_MAX_PARTS];
-  for (u32 k = 0; k < parts; k++) h_lo[k] = (u32)part_lower_bound(k, scale);
+  for (u32 k = 0; k < parts; k++) h_lo[k] = (u32)(part_lower_bound(k, scale) << shift);
   HIP_CHECK(hipMemsetAsync(d.get(), 0, 2 * (size_t)parts * sizeof(unsigned long long), c.stream));
   HIP_CHECK(hipMemcpyAsync(lo.get(), h_lo, parts * sizeof(u32), hipMemcpyHostToDevice, c.stream));
   const u32 nblk = ceil_div(count, PT_THREADS * PT_ITEMS);
   Phase ph(c, "dist_partition", (double)count * 12);
   unsigned long long h_cnt[PT_MAX_PARTS];
   if (count > 0) {
-    hipLaunchKernelGGL(k_part_count, dim3(nblk), dim3(PT_THREADS), 0, c.stream, in, count, scale, parts, d.get());
+    hipLaunchKernelGGL(k_part_count, dim3(nblk), dim3(PT_THREADS), 0, c.stream, in, count, scale, shift, parts, d.get());
     HIP_CHECK(hipGetLastError());
   }
   HIP_CHECK(hipMemcpyAsync(h_cnt, d.get(), parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
@@ -98,7 +99,7 @@ void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, 
   if (acc != count) fail(BWT_HIP_EINTERNAL, "partition: counted %llu of %lu values", acc, (unsigned long)count);
   if (count > 0) {
     HIP_CHECK(hipMemcpyAsync(d.get() + parts, h_cur, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(k_part_scatter, dim3(nblk), dim3(PT_THREADS), 0, c.stream, in, count, scale, parts, lo.get(),
+    hipLaunchKernelGGL(k_part_scatter, dim3(nblk), dim3(PT_THREADS), 0, c.stream, in, count, scale, shift, parts, lo.get(),
                        d.get() + parts, out, perm);
     HIP_CHECK(hipGetLastError());
     c.sync();  // h_cur is on the stack
@@ -177,11 +178,13 @@ void wire_unpack2(Ctx &c, const u8 *packed, u64 count, u8 *dst) {
   HIP_CHECK(hipGetLastError());
 }
 
-void partition_bounds(u64 m, u32 parts, i64 *lo_out) {
-  const u64 scale = (((u64)parts) << 32) / (m + 1);
-  for (u32 k = 0; k < parts; k++) lo_out[k] = (i64)part_lower_bound(k, scale);
+void partition_bounds(u64 m, u32 parts, i64 *lo_out, int shift) {
+  const u64 scale = (((u64)parts) << 32) / ((m >> shift) + 1);
+  for (u32 k = 0; k < parts; k++) lo_out[k] = (i64)(part_lower_bound(k, scale) << shift);
   lo_out[parts] = (i64)(m + 1);
 }
+
+int partition_shift(const Ctx &c, u64 m) { return gap_grouping_applies(c, m) ? 13 : 0; }
 
 // samples kept among the first i of a merge's sample sequence (left samples by position, then right samples by
 // position): the reference's serial selection (include/bwt.h:412, :436) in closed form, as in k_resample of merge.hip
@@ -263,13 +266,13 @@ u64 samples_taken_before(u64 i, u64 A, u64 B) {
   return t < i ? t : i;
 }
 
-void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts) {
+void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts, int shift) {
   DBuf<u32> rel(c, n ? n : 1);
   if (n) {
     hipLaunchKernelGGL(k_rel_u32, dim3(ceil_div(n, 256)), dim3(256), 0, c.stream, rank_abs, n, (u32)a, rel.get());
     HIP_CHECK(hipGetLastError());
   }
-  partition_by_left_rank(c, rel.get(), n, m, members, queries, counts, perm);
+  partition_by_left_rank(c, rel.get(), n, m, members, queries, counts, perm, shift);
   c.sync();
 }
 

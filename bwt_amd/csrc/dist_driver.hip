@@ -205,34 +205,106 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   c.sync();
   lb->e_char = *(u8 *)c.h_scalars;
 
+  // Where the gap histogram groups its values in two passes (left blocks of 2^21 suffixes and more), the g values
+  // travel grouped: the sender runs that grouping on the values of its own chains and sends each part the 16-bit
+  // words of the part's buckets plus the buckets' bounds, half the bytes of the values themselves, and the receiver
+  // counts the words of all senders bucket by bucket.  Parts then begin at multiples of 8192 left ranks.
+  const int shift = partition_shift(c, (u64)m);
+  const bool grouped = shift != 0;
+  std::vector<i64> lo((size_t)G + 1);
+  partition_bounds((u64)m, (u32)G, lo.data(), shift);
+
   // 2. LF chains of this member's share of the right positions
   const i64 p_lo = cpos + (i64)k * r / G, p_hi = cpos + (i64)(k + 1) * r / G;
-  DBuf<u32> gt(c, (size_t)(p_hi - p_lo > 0 ? p_hi - p_lo : 1));
-  if (p_hi > p_lo) {
-    DBuf<u32> g0;
+  const i64 cnt = p_hi - p_lo;
+  DBuf<u32> gt(c, (size_t)(cnt > 0 ? cnt : 1)), g0;
+  u64 total = 0;  // entries of g0: the chains' values in step-major order, the short last chain filled up with m + 1
+  if (cnt > 0) {
     ChainLayout lay = run_chains(c, *lb, p_lo, p_hi, seg, g0);
     chains_text_order(c, lay, g0.get(), gt.get());
+    total = (u64)lay.seg * lay.n_chains;
   }
+  if (!grouped) g0.reset();
   lb->wm = WaveletDev();  // the rank structure is not needed any more; L is (step 4)
 
   // 3. every g value to the member that owns its part, then the right symbols each part interleaves
-  const i64 cnt = p_hi - p_lo;
-  DBuf<u32> g_parts(c, (size_t)(cnt > 0 ? cnt : 1));
-  std::vector<i64> counts((size_t)G, 0);
-  partition_by_left_rank(c, gt.get(), (u64)cnt, (u64)m, (u32)G, g_parts.get(), counts.data());
-  std::vector<i64> table = g.all_gather(counts);  // table[src * G + part]
   std::vector<i64> R((size_t)G, 0), rb(1, 0), send_b((size_t)G), recv_b((size_t)G);
-  for (int d = 0; d < G; d++)
-    for (int s = 0; s < G; s++) R[(size_t)d] += table[(size_t)s * (size_t)G + (size_t)d];
+  DBuf<u32> g_in, st_in, w_off;
+  DBuf<u16> w_in;
+  u32 nbk = 0;  // buckets of this member's part
+  if (!grouped) {
+    DBuf<u32> g_parts(c, (size_t)(cnt > 0 ? cnt : 1));
+    std::vector<i64> counts((size_t)G, 0);
+    partition_by_left_rank(c, gt.get(), (u64)cnt, (u64)m, (u32)G, g_parts.get(), counts.data());
+    std::vector<i64> table = g.all_gather(counts);  // table[src * G + part]
+    for (int d = 0; d < G; d++)
+      for (int s = 0; s < G; s++) R[(size_t)d] += table[(size_t)s * (size_t)G + (size_t)d];
+    g_in = DBuf<u32>(c, (size_t)(R[(size_t)k] > 0 ? R[(size_t)k] : 1));
+    for (int j = 0; j < G; j++) {
+      send_b[(size_t)j] = counts[(size_t)j] * 4;
+      recv_b[(size_t)j] = table[(size_t)j * (size_t)G + (size_t)k] * 4;
+    }
+    g.all_to_all((const u8 *)g_parts.get(), send_b, (u8 *)g_in.get(), recv_b);
+  } else {
+    const u32 nb = (u32)(((u64)m >> shift) + 1);  // buckets of the whole left block
+    std::vector<u32> B((size_t)G + 1, nb);        // part d owns the buckets B[d] .. B[d+1]-1
+    for (int d = 0; d < G; d++) B[(size_t)d] = (u32)((u64)lo[(size_t)d] >> shift) < nb ? (u32)((u64)lo[(size_t)d] >> shift) : nb;
+    const size_t nst = gap_group16_starts((u64)m);
+    DBuf<u32> start(c, nst);
+    if (total > 0) {
+      DBuf<u32> g1(c, (size_t)total);
+      gap_group16(c, g0.get(), g1.get(), total, (u64)m, start.get());
+      c.sync();  // g1 dies here
+    } else {
+      HIP_CHECK(hipMemsetAsync(start.get(), 0, nst * sizeof(u32), c.stream));
+    }
+    std::vector<u32> h_st((size_t)G + 1);
+    for (int d = 0; d <= G; d++) HIP_CHECK(hipMemcpyAsync(&h_st[(size_t)d], start.get() + B[(size_t)d], sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    // the fillers lie in the bucket of m + 1: the last part's last bucket (its receiver skips them), or one past all
+    const i64 fillers_in = ((((u64)m + 1) >> shift) < nb) ? (i64)total - cnt : 0;
+    std::vector<i64> words((size_t)G + 1, 0);
+    for (int d = 0; d < G; d++) words[(size_t)d] = (i64)h_st[(size_t)d + 1] - (i64)h_st[(size_t)d];
+    words[(size_t)G] = fillers_in;
+    std::vector<i64> table = g.all_gather(words);  // table[src * (G + 1) + part], [.. + G] = the sender's fillers
+    const size_t W = (size_t)G + 1;
+    i64 in_words = 0;
+    std::vector<u32> h_off((size_t)G, 0);
+    for (int s = 0; s < G; s++) {
+      for (int d = 0; d < G; d++) R[(size_t)d] += table[(size_t)s * W + (size_t)d];
+      R[(size_t)G - 1] -= table[(size_t)s * W + (size_t)G];
+      h_off[(size_t)s] = (u32)in_words;
+      in_words += table[(size_t)s * W + (size_t)k];
+    }
+    w_in = DBuf<u16>(c, (size_t)in_words + 8);
+    for (int j = 0; j < G; j++) {
+      send_b[(size_t)j] = words[(size_t)j] * 2;
+      recv_b[(size_t)j] = table[(size_t)j * W + (size_t)k] * 2;
+    }
+    g.all_to_all((const u8 *)g0.get(), send_b, (u8 *)w_in.get(), recv_b);  // a part's buckets follow the part before it
+    // the bounds of every part's buckets (piece d = start[B[d] .. B[d+1]], one entry more than buckets)
+    nbk = B[(size_t)k + 1] - B[(size_t)k];
+    size_t st_total = 0;
+    for (int d = 0; d < G; d++) st_total += (size_t)(B[(size_t)d + 1] - B[(size_t)d]) + 1;
+    DBuf<u32> st_out(c, st_total);
+    size_t at = 0;
+    for (int d = 0; d < G; d++) {
+      const size_t len = (size_t)(B[(size_t)d + 1] - B[(size_t)d]) + 1;
+      HIP_CHECK(hipMemcpyAsync(st_out.get() + at, start.get() + B[(size_t)d], len * sizeof(u32), hipMemcpyDeviceToDevice, c.stream));
+      send_b[(size_t)d] = (i64)len * 4;
+      recv_b[(size_t)d] = ((i64)nbk + 1) * 4;
+      at += len;
+    }
+    st_in = DBuf<u32>(c, (size_t)G * ((size_t)nbk + 1));
+    g.all_to_all((const u8 *)st_out.get(), send_b, (u8 *)st_in.get(), recv_b);
+    w_off = DBuf<u32>(c, (size_t)G);
+    HIP_CHECK(hipMemcpyAsync(w_off.get(), h_off.data(), (size_t)G * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+    c.sync();  // h_off is on the stack; the grouped values and the bounds that were sent die here
+    g0.reset();
+  }
   for (int d = 0; d < G; d++) rb.push_back(rb.back() + R[(size_t)d]);
   if (rb.back() != r) fail(BWT_HIP_EINTERNAL, "parts hold %ld of %ld right suffixes", (long)rb.back(), (long)r);
   const i64 rn = R[(size_t)k];
-  DBuf<u32> g_in(c, (size_t)(rn > 0 ? rn : 1));
-  for (int j = 0; j < G; j++) {
-    send_b[(size_t)j] = counts[(size_t)j] * 4;
-    recv_b[(size_t)j] = table[(size_t)j * (size_t)G + (size_t)k] * 4;
-  }
-  g.all_to_all((const u8 *)g_parts.get(), send_b, (u8 *)g_in.get(), recv_b);
   DBuf<u8> rL(c, (size_t)(rn > 0 ? rn : 1));
   for (int d = 0; d < G; d++) {
     send_b[(size_t)d] = k >= q ? overlap(roff[(size_t)(k - q)], roff[(size_t)(k - q + 1)], rb[(size_t)d], rb[(size_t)d + 1]) : 0;
@@ -268,8 +340,6 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   }
 
   // 4. this part's slice of the merged block
-  std::vector<i64> lo((size_t)G + 1);
-  partition_bounds((u64)m, (u32)G, lo.data());
   auto clampm = [&](i64 v) { return v < m ? v : m; };
   const i64 i_lo = clampm(lo[(size_t)k]), i_hi = clampm(lo[(size_t)k + 1]), mL = i_hi - i_lo;
   std::unique_ptr<DistBlock> out(new DistBlock());
@@ -280,11 +350,13 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   for (int d = 0; d < G; d++) out->sizes.push_back(clampm(lo[(size_t)d + 1]) - clampm(lo[(size_t)d]) + R[(size_t)d]);
   out->L = DBuf<u8>(c, (size_t)(mL + rn > 0 ? mL + rn : 1));
   DBuf<u32> S(c, (size_t)mL + 1);
-  {
+  if (!grouped) {
     DBuf<u32> scratch(c, (size_t)(rn > 0 ? rn : 1));
     gap_prefix(c, g_in.get(), scratch.get(), (u64)rn, (u64)mL, S.get());
-    merge_symbols(c, lb->L.get() + i_lo, (u64)mL, rL.get(), (u64)rn, S.get(), out->L.get());
+  } else {
+    gap_prefix_grouped(c, w_in.get(), w_off.get(), st_in.get(), (u32)G, nbk, (u64)mL, S.get());
   }
+  merge_symbols(c, lb->L.get() + i_lo, (u64)mL, rL.get(), (u64)rn, S.get(), out->L.get());
 
   // 5. samples stay with their holders: requests out, answers back, each holder thins its own
   {
@@ -298,7 +370,7 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
     const u64 A = (u64)(ns_out - 1), B = nn ? nn - 1 : 0;
     DBuf<u32> queries(c, mine ? mine : 1), perm(c, mine ? mine : 1);
     std::vector<i64> ask((size_t)G, 0);
-    if (k < q) samples_route_left(c, blk->samp_rank.get(), mine, a, (u64)m, (u32)G, queries.get(), perm.get(), ask.data());
+    if (k < q) samples_route_left(c, blk->samp_rank.get(), mine, a, (u64)m, (u32)G, queries.get(), perm.get(), ask.data(), shift);
     else samples_route_right(c, blk->samp_pos.get(), mine, cpos, (u64)r, (u32)G, queries.get(), ask.data());
     std::vector<i64> asked = g.all_gather(ask);  // asked[src * G + member]
     u64 in_left = 0, in_right = 0;

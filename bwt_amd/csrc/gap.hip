@@ -367,10 +367,86 @@ __global__ void __launch_bounds__(GH_THREADS)
     if (base + j <= m) S[base + j] = hist[gh_slot(j)];
 }
 
+// The same for a part of a merge that is spread over several GPUs: the values come grouped from `sources` senders,
+// each with the grouping of its own values (gap_group16).  Sender s's words lie at words[word_off[s] ...), bucket b
+// of them at [st[b] - st[0], st[b + 1] - st[0]) with st = starts + s * (nbk + 1); the part has nbk buckets, and the
+// launch has one workgroup more than that when the part's last gap index opens a bucket of its own (then empty).
+__global__ void __launch_bounds__(GH_THREADS)
+    k_bucket_prefix16_multi(const u16 *__restrict__ words, const u32 *__restrict__ word_off, const u32 *__restrict__ starts,
+                            u32 sources, u32 nbk, int low, u32 m, u32 *__restrict__ S) {
+  __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x;
+  const u32 width = 1u << low;
+  const u32 bucket = blockIdx.x, bk = bucket < nbk ? bucket : nbk;
+  for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
+  __syncthreads();
+  const u64 base = (u64)bucket << low;
+  u32 below = 0;  // values of all senders in lower buckets
+  for (u32 s = 0; s < sources; s++) {
+    const u32 *st = starts + (size_t)s * (nbk + 1);
+    const u32 first = st[0];
+    below += st[bk] - first;
+    if (bucket >= nbk) continue;
+    const u32 lo = word_off[s] + (st[bucket] - first), hi = word_off[s] + (st[bucket + 1] - first);
+    for (u32 i0 = lo + tid; i0 < hi; i0 += 8 * GH_THREADS) {
+      u32 g[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const u32 i = i0 + k * GH_THREADS;
+        g[k] = i < hi ? (u32)words[i] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (g[k] != 0xFFFFFFFFu && base + g[k] <= m) atomicAdd(&hist[gh_slot(g[k])], 1u);  // fillers (above m) are skipped
+    }
+  }
+  __syncthreads();
+  const u32 per = (width + GH_THREADS - 1) / GH_THREADS;
+  const u32 j0 = tid * per;
+  u32 mine = 0;
+  for (u32 j = j0; j < j0 + per && j < width; j++) mine += hist[gh_slot(j)];
+  u32 all;
+  u32 run = below + block_scan_incl<OpSum>(mine, scan_s, &all) - mine;
+  for (u32 j = j0; j < j0 + per && j < width; j++) {
+    run += hist[gh_slot(j)];
+    hist[gh_slot(j)] = run;
+  }
+  __syncthreads();
+  for (u32 j = tid; j < width; j += GH_THREADS)
+    if (base + j <= m) S[base + j] = hist[gh_slot(j)];
+}
+
 static int bits_for(u64 x) {
   int b = 1;
   while (b < 64 && (x >> b)) b++;
   return b;
+}
+
+// Left blocks whose gap indices have 9 to 18 bits above the 13 that a bucket spans take the two-pass grouping
+// (gap_sort_lean): 2^21 to 2^31 - 1 gap indices.
+bool gap_grouping_applies(const Ctx &c, u64 m) {
+  const int high = bits_for(m + 1) - GH_LOW_MAX;
+  return c.gap_lean && high > 8 && high <= 18;
+}
+
+size_t gap_group16_starts(u64 m) { return ((size_t)1 << (bits_for(m + 1) - GH_LOW_MAX)) + 1; }
+
+void gap_group16(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *start) {
+  const int high = bits_for(m + 1) - GH_LOW_MAX;
+  const int b2 = (high + 1) / 2, b1 = high - b2;
+  u32 *keys[2] = {g0, g1};
+  Phase ph(c, "gap_histogram", (double)total * (12 + 10));
+  gap_sort_lean(c, keys, total, GH_LOW_MAX, b1, b2, start);
+}
+
+void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32 *starts, u32 sources, u32 nbk, u64 m, u32 *S) {
+  const u32 n_buckets = (u32)((m >> GH_LOW_MAX) + 1);
+  if (n_buckets != nbk && n_buckets != nbk + 1) fail(BWT_HIP_EINTERNAL, "grouped prefix: %u buckets for %lu gap indices", nbk, (unsigned long)(m + 1));
+  KernelTimer kt(c, "gap:k_bucket_prefix", (double)(m + 1) * 4);
+  hipLaunchKernelGGL(k_bucket_prefix16_multi, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, words, word_off, starts, sources, nbk,
+                     GH_LOW_MAX, (u32)m, S);
+  HIP_CHECK(hipGetLastError());
 }
 
 // LF-mapping chains of the right positions [ra, rb) against the block l (ra >= l.b; the positions need

@@ -375,13 +375,24 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg, DBuf<u32> &g0)
 void chains_text_order(Ctx &c, const ChainLayout &lay, const u32 *g0, u32 *out);
 void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S);
 void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 *S, u8 *out);
+// The histogram's grouping on its own, for merges spread over GPUs whose g values travel grouped (gap.hip).
+// gap_group16: g0 (total values in [0, m + 1], destroyed; g1 scratch of the same size) -> the values' low 13 bits
+// as 16-bit words in g0, grouped by bucket = value >> 13; start[k] = first word of bucket k (gap_group16_starts(m)
+// entries).  gap_prefix_grouped: S[i], i in [0, m], from the grouped words of `sources` senders (k_bucket_prefix16_multi).
+bool gap_grouping_applies(const Ctx &c, u64 m);
+size_t gap_group16_starts(u64 m);
+void gap_group16(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *start);
+void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32 *starts, u32 sources, u32 nbk, u64 m, u32 *S);
 // merge.hip
 Block *merge_blocks(Ctx &c, Block &l, Block &r, GapResult &gap, i64 ns);
 
 // dist.hip: pieces of a merge spread over several GPUs
-void partition_bounds(u64 m, u32 parts, i64 *lo_out);
+// shift: parts are cut at multiples of 2^shift left ranks (0: anywhere)
+void partition_bounds(u64 m, u32 parts, i64 *lo_out, int shift = 0);
+int partition_shift(const Ctx &c, u64 m);  // 13 where the g values of a merge travel grouped by gap bucket, else 0
 // perm (may be null): perm[x] = index in `in` of the value that went to out[x]
-void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm = nullptr);
+void partition_by_left_rank(Ctx &c, const u32 *in, u64 count, u64 m, u32 parts, u32 *out, i64 *counts_host, u32 *perm = nullptr,
+                            int shift = 0);
 // Symbols between GPUs as two bits each (texts whose symbols span at most four consecutive values): `count`
 // symbols at src (any alignment) -> wire_bytes(count) bytes at packed, and back to dst (any alignment).  The
 // unpacking kernel reads up to WIRE_PAD bytes past the packed stream: buffers that receive one are that much longer.
@@ -394,7 +405,8 @@ void wire_unpack2(Ctx &c, const u8 *packed, u64 count, u8 *dst);
 // left: queries[x] = left rank - first left rank of the answering part, perm[x] = the sample it belongs to;
 // right: queries[i] = pos[i] - first position of the answering member's chains (samples are in position order, so
 // the groups are too).  counts[d] = requests for member d.
-void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts);
+void samples_route_left(Ctx &c, const u32 *rank_abs, u64 n, i64 a, u64 m, u32 members, u32 *queries, u32 *perm, i64 *counts,
+                        int shift = 0);
 void samples_route_right(Ctx &c, const u32 *pos, u64 n, i64 cpos, u64 r, u32 members, u32 *queries, i64 *counts);
 // ans[x]: for the first n_left requests the new absolute rank of the left sample, for the n_right after them g
 void samples_answer(Ctx &c, const u32 *q, u64 n_left, u64 n_right, const u32 *S_local, u64 i_lo, u64 right_before, i64 a,

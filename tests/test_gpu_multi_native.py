@@ -80,3 +80,20 @@ def test_rccl_transport_with_one_rank(ctx):
         assert (x == y).all()
     s.free()
     t.close()
+
+
+@pytest.mark.parametrize("n,world", [(2 * 2 ** 21 - 6, 2), (2 * (2 ** 21 + 8191), 2), (2 * (2 ** 21 + 8192) + 1, 2), (4 * 2 ** 21 + 3, 4)])
+def test_native_multi_grouped_g_exchange_boundaries(ctx, n, world):
+    """Left blocks of 2^21 suffixes and more send their g values grouped by gap bucket (16-bit words + bucket bounds,
+    parts cut at multiples of 8192 left ranks); smaller ones send the values.  Around the switch, with the last gap
+    index at the end of a bucket and in a bucket of its own, with chains whose last one is short (fillers), and with
+    both kinds of merge in one tree: the single-context build's L, special ranks and samples."""
+    ctx.gen_text(n, 9, 4)
+    T = ctx.get_text()
+    th, ns = -(-n // world), 5000
+    one = ctx.pmbwt(th, ns, 1000)
+    L1, info1, (r1, p1) = one.L, (one.s_rank, one.e_rank), one.samples()
+    one.free()
+    L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, ns, 1000)
+    assert used == world and (s_rank, e_rank) == info1
+    assert (L == L1).all() and (r == r1).all() and (p == p1).all()
