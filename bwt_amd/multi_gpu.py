@@ -158,9 +158,39 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     total_leaves = world * lpr
     depth = total_leaves.bit_length() - 1
     ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
-    # "dist" (default): every merge runs on all GPUs of its subtree and the result stays spread over the GPUs
-    # (bwt_amd/dist_merge.py); "tree": right blocks move to the left owner, the result ends on rank 0
-    algo = os.environ.get("BWT_MGPU_ALGO", "dist")
+    # "native" (default): every merge runs on all GPUs of its subtree and the result stays spread over the GPUs, the
+    # schedule in C++ (bwt_hip_dist_pmbwt) over the library's own RCCL communicator; "dist": the same schedule in
+    # Python over torch.distributed (bwt_amd/dist_merge.py; its g values travel as 32-bit words); "tree": right blocks
+    # move to the left owner, the result ends on rank 0
+    algo = os.environ.get("BWT_MGPU_ALGO", "native")
+    transport, fallback = None, None
+    if algo == "native":
+        # the library's communicator comes up on every rank or the run takes the torch.distributed schedule instead:
+        # the ranks agree on that before any build starts
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            if rank == 0:
+                uid.copy_(torch.from_numpy(bwt_amd.Transport.rccl_unique_id()))
+        except Exception as e:  # librccl.so not loadable
+            fallback = repr(e)
+            ok.zero_()
+        dist.broadcast(uid, 0)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()):
+            try:
+                transport = bwt_amd.Transport.rccl(ctx, uid.cpu().numpy(), rank, world)
+            except Exception as e:
+                fallback = repr(e)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            if transport is not None:
+                transport.close()
+                transport = None
+            fallback = fallback or "another rank could not bring the library's RCCL communicator up"
+            print("rank %d: native transport unavailable (%s): torch.distributed schedule instead" % (rank, fallback), file=sys.stderr)
+            algo = "dist"
     if algo == "dist":
         from bwt_amd import dist_merge
         dops = dist_merge.HipDistOps(ctx, ns, args.seg, dev)
@@ -179,14 +209,10 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             ctx.sync()
             return _Held(d)
     elif algo == "native":
-        # the same schedule in C++ (bwt_hip_dist_pmbwt) over the library's own RCCL transport: ncclSend / ncclRecv
-        # on a communicator of its own; torch.distributed only carries the communicator's id and the timing
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            uid.copy_(torch.from_numpy(bwt_amd.Transport.rccl_unique_id()))
-        dist.broadcast(uid, 0)
-        transport = bwt_amd.Transport.rccl(ctx, uid.cpu().numpy(), rank, world)
+        # ncclSend / ncclRecv on a communicator of the library's own; torch.distributed only carried the communicator's
+        # id and carries the timing
         th_native = leaf_threshold(n, total_leaves)
+        ctx.dist_pmbwt(transport, th_native, min(ns, 1000), args.seg).free()  # connections between the ranks come up at first use
 
         def step():
             s = ctx.dist_pmbwt(transport, th_native, ns, args.seg)
@@ -232,7 +258,7 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
             "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
-                                    "subtree (RCCL point-to-point + all-to-all); L stays sliced over the GPUs, every GPU keeps the samples of its own text range"
+                                    "subtree (RCCL send/recv); L stays sliced over the GPUs, every GPU keeps the samples of its own text range"
                                     if algo in ("dist", "native") else
                                     "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0")
                                    % (n, total_leaves, world),
@@ -241,11 +267,13 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
                        "parallelism": "leaf-sharded x%d, %s" % (world, {"dist": "distributed merges (torch.distributed)",
                                                                         "native": "distributed merges (C++ driver, RCCL send/recv)"}.get(algo, "pairwise merge tree"))},
             # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
-            "roofline": roofline(timers), "cpu_baseline": None,
+            "roofline": roofline(timers), "cpu_baseline": None, "schedule": algo, "native_transport_fallback": fallback,
             "phases_rank0": phase_table(timers, args.steps),
         }
     if last is not None:
         last.free()
+    if transport is not None:
+        transport.close()
     ctx.close()
     dist.destroy_process_group()
     if rank == 0:
