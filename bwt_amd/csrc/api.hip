@@ -644,7 +644,10 @@ int bwt_hip_block_get_samples(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, int64
   Ctx &c = ctx->c;
   HIP_CHECK(hipSetDevice(c.device));
   i64 k = blk->n_samp < cap ? blk->n_samp : cap;
-  if (k > 0) {
+  if (k >= ((i64)1 << 20)) {
+    // large sets cross the link as the 32-bit words they are on the device and are widened by host threads
+    download_samples32(c, blk->samp_rank.get(), blk->samp_pos.get(), k, blk->a, rank_out, pos_out);
+  } else if (k > 0) {
     // widened to the reference's idx_t on the device, then one copy per array straight into the caller's memory
     DBuf<i64> wr(c, (size_t)k), wp(c, (size_t)k);
     hipLaunchKernelGGL(k_widen_samples, dim3(ceil_div(k, 256)), dim3(256), 0, c.stream, blk->samp_rank.get(),

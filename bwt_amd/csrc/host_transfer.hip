@@ -212,6 +212,39 @@ void download_packed(Ctx &c, const u8 *L_dev, i64 n, u32 min_sym, i64 foreign, u
   c.sync();
 }
 
+// A block's samples to host memory: 32-bit words over the link (half the bytes of the caller's 64-bit arrays),
+// widened by host threads while the next chunk travels.  rank_out[i] = rank[i] + a, pos_out[i] = pos[i].
+void download_samples32(Ctx &c, const u32 *rank, const u32 *pos, i64 k, i64 a, i64 *rank_out, i64 *pos_out) {
+  prepare_packed_upload(c);
+  const i64 per = (c.xfer_chunk / 4) / 8;  // samples per staging buffer: 4 bytes of rank + 4 of position each
+  const i64 chunks = (k + per - 1) / per;
+  const int nt = host_threads(k);
+  auto issue = [&](i64 j) {
+    const i64 off = j * per, len = k - off < per ? k - off : per;
+    u32 *st = reinterpret_cast<u32 *>(c.xfer_stage[j % XF_SLOTS]);
+    HIP_CHECK(hipMemcpyAsync(st, rank + off, (size_t)len * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(st + per, pos + off, (size_t)len * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipEventRecord(c.xfer_ev[j % XF_SLOTS], c.stream));
+  };
+  auto finish = [&](i64 j) {
+    const i64 off = j * per, len = k - off < per ? k - off : per;
+    const u32 *st = reinterpret_cast<const u32 *>(c.xfer_stage[j % XF_SLOTS]);
+    HIP_CHECK(hipEventSynchronize(c.xfer_ev[j % XF_SLOTS]));
+    on_threads(nt, [&](int t) {
+      const i64 lo = len * t / nt, hi = len * (t + 1) / nt;
+      for (i64 i = lo; i < hi; i++) {
+        rank_out[off + i] = (i64)st[i] + a;
+        pos_out[off + i] = (i64)st[per + i];
+      }
+    });
+  };
+  for (i64 j = 0; j < chunks + 2; j++) {  // two chunks in flight while the host widens the one before them
+    if (j < chunks) issue(j);
+    if (j >= 2) finish(j - 2);
+  }
+  c.sync();
+}
+
 void prepare_packed_upload(Ctx &c) {
   if (c.xfer_chunk > XF_CHUNK) c.xfer_chunk = XF_CHUNK;
   if (c.xfer_chunk < 4096) c.xfer_chunk = 4096;

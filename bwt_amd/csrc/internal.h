@@ -433,6 +433,7 @@ void probe_symbol_range(const u8 *T, i64 n, int *lo, int *hi);
 void prepare_packed_upload(Ctx &c);
 void upload_text_packed(Ctx &c, const u8 *T_host, i64 n, u32 min_sym, u32 span, u8 *dpacked, std::string *err);
 void download_packed(Ctx &c, const u8 *L_dev, i64 n, u32 min_sym, i64 foreign, u8 *L_host);
+void download_samples32(Ctx &c, const u32 *rank, const u32 *pos, i64 k, i64 a, i64 *rank_out, i64 *pos_out);
 
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
 void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);

@@ -211,3 +211,27 @@ def test_pmbwt_host_rejects_bad_texts(ctx):
     # the context is usable afterwards
     ctx.set_text(np.frombuffer(b"banana\0", dtype=np.uint8))
     assert bytes(ctx.pmbwt(10, 2).L) == b"annb\0aa"
+
+
+def test_large_sample_set_reaches_the_host_intact(ctx):
+    """Sample sets of 2^20 entries and more cross the link as 32-bit words in chunks and are widened by host threads
+    (bwt_hip_block_get_samples): ranks and positions of the oracle, for a block that does not start at 0 too."""
+    from oracle import gen_text
+    n, ns = 2500000, 1100000
+    T = gen_text(n, 21, 4)
+    ctx.set_text(T)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=4, bwt_rec_threshold=n // 2 + 1, ssa_n_samples=ns)
+    ob = Oracle.pmbwt(T, o)
+    blk = ctx.pmbwt(n // 2 + 1, ns)
+    r, p = blk.samples()
+    orr, op = ob.samples()
+    assert len(r) == ns and (r == orr).all() and (p == op).all()
+    blk.free()
+    # a leaf of its own range: ranks are relative to the block + its first position
+    a, b = 100001, 2400000
+    leaf = ctx.leaf(a, b, b - a)  # every position sampled
+    r, p = leaf.samples()
+    assert len(p) == b - a and (p == np.arange(a, b)).all()
+    L = leaf.L
+    assert (L[r - a] == T[p - 1]).all()
+    leaf.free()
