@@ -37,3 +37,24 @@ def test_random_small_configurations(ctx, seed):
         for x, y in zip(blk.samples(), ob.samples()):
             assert len(x) == len(y) and (x == y).all(), tag
         blk.free()
+
+
+def test_random_multi_rank_configurations(ctx):
+    """The same for the C++ multi-GPU driver (tools/fuzz_multi.py holds the generator): random lengths, alphabets,
+    rank counts (threads that share the GPU), leaf sizes, sample counts and chain lengths against the single-context
+    build of the same tree; some texts large enough for the grouped exchange of the g values."""
+    import bwt_amd
+    spec = importlib.util.spec_from_file_location("fuzz_multi", os.path.join(os.path.dirname(HERE), "tools", "fuzz_multi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(5)
+    for k in range(30):
+        T, world, th, ns, seg = mod.make(rng)
+        tag = "case %d: n=%d symbols %d..%d world=%d th=%d ns=%d seg=%d" % (k, len(T), T[:-1].min(), T[:-1].max(), world, th, ns, seg)
+        ctx.set_text(T)
+        one = ctx.pmbwt(th, ns, seg)
+        L1, info1, (r1, p1) = one.L, (one.s_rank, one.e_rank), one.samples()
+        one.free()
+        L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, ns, seg)
+        assert (s_rank, e_rank) == info1 and (L == L1).all(), tag
+        assert len(r) == len(r1) and (r == r1).all() and (p == p1).all(), tag
