@@ -234,15 +234,29 @@ __global__ void k_sample_g(const u32 *__restrict__ g, const u32 *__restrict__ sp
   out[k] = g[(u64)(end - 1 - j) * n_chains + c];
 }
 
-// g in text order (test tap): out[j - ra] = g_j
-__global__ void k_g_text_order(const u32 *__restrict__ g, u64 ra, u64 rb, u32 seg, u32 n_chains,
-                               u32 *__restrict__ out) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rb - ra) return;
-  u32 c = (u32)(i / seg);
-  u64 end = (u64)(c + 1) * seg;
-  if (end > rb - ra) end = rb - ra;
-  out[i] = g[(end - 1 - i) * n_chains + c];
+// g in text order: out[j - ra] = g_j.  The chains wrote g step-major ([step][chain]: a wavefront's 64 chains store 64
+// consecutive words); text order is chain-major with the steps reversed, so this is a transpose, done through LDS in
+// tiles of 64 chains x 64 steps: rows of the tile are read along the chains, columns written along the text.
+constexpr int GT_TILE = 64;
+__global__ void __launch_bounds__(256) k_g_text_order(const u32 *__restrict__ g, u64 rn, u32 seg, u32 n_chains, u32 tiles_c,
+                                                      u32 *__restrict__ out) {
+  __shared__ u32 tile[GT_TILE][GT_TILE + 1];
+  const u32 c0 = (blockIdx.x % tiles_c) * GT_TILE, s0 = (blockIdx.x / tiles_c) * GT_TILE;
+  const u32 tx = threadIdx.x & (GT_TILE - 1), ty = threadIdx.x / GT_TILE;  // 64 x 4
+  for (u32 s = ty; s < GT_TILE; s += 4) {
+    const u32 step = s0 + s, c = c0 + tx;
+    if (step < seg && c < n_chains) tile[s][tx] = g[(u64)step * n_chains + c];
+  }
+  __syncthreads();
+  for (u32 cc = ty; cc < GT_TILE; cc += 4) {
+    const u32 c = c0 + cc;
+    if (c >= n_chains) break;
+    const u64 begin = (u64)c * seg;
+    const u64 end = begin + seg < rn ? begin + seg : rn;  // the last chain may be short
+    // position end - 1 - step holds the value of `step`; lanes run along the text: step = s0 + 63 - tx downwards
+    const u32 step = s0 + (GT_TILE - 1 - tx);
+    if (step < seg && begin + step < end) out[end - 1 - step] = tile[GT_TILE - 1 - tx][cc];
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -533,8 +547,10 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
 }
 
 void chains_text_order(Ctx &c, const ChainLayout &lay, const u32 *g0, u32 *out) {
-  hipLaunchKernelGGL(k_g_text_order, dim3(ceil_div(lay.rb - lay.ra, 256)), dim3(256), 0, c.stream, g0, lay.ra, lay.rb,
-                     lay.seg, lay.n_chains, out);
+  const u32 tiles_c = ceil_div(lay.n_chains, GT_TILE), tiles_s = ceil_div(lay.seg, GT_TILE);
+  if ((u64)tiles_c * tiles_s >= (1ull << 31)) fail(BWT_HIP_EINVAL, "chains: %u chains of %u steps are too many tiles", lay.n_chains, lay.seg);
+  hipLaunchKernelGGL(k_g_text_order, dim3(tiles_c * tiles_s), dim3(256), 0, c.stream, g0, lay.rb - lay.ra, lay.seg, lay.n_chains,
+                     tiles_c, out);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--parts", type=int, default=8)
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--left_leaves", type=int, default=4)
+    ap.add_argument("--seg", type=int, default=0, help="build_gap_segment_sz (0: the default, 1024)")
     args = ap.parse_args()
     import torch
     import bwt_amd
@@ -31,7 +32,7 @@ def main():
     a, c, b = 0, n // 2, n
     m, r = c - a, b - c
     ns = max(1000, n // 160)
-    ops = dist_merge.HipDistOps(ctx, ns, 0, dev)
+    ops = dist_merge.HipDistOps(ctx, ns, args.seg, dev)
 
     def timed(name, f):
         torch.cuda.synchronize()
