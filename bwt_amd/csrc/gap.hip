@@ -385,35 +385,60 @@ __global__ void __launch_bounds__(GH_THREADS)
 // each with the grouping of its own values (gap_group16).  Sender s's words lie at words[word_off[s] ...), bucket b
 // of them at [st[b] - st[0], st[b + 1] - st[0]) with st = starts + s * (nbk + 1); the part has nbk buckets, and the
 // launch has one workgroup more than that when the part's last gap index opens a bucket of its own (then empty).
+constexpr u32 GH_MAX_SOURCES = 256;
 __global__ void __launch_bounds__(GH_THREADS)
     k_bucket_prefix16_multi(const u16 *__restrict__ words, const u32 *__restrict__ word_off, const u32 *__restrict__ starts,
                             u32 sources, u32 nbk, int low, u32 m, u32 *__restrict__ S) {
   __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
   __shared__ u32 scan_s[17];
+  // the bucket's words of all senders as one index space: sender s holds the indices [cum[s], cum[s + 1]), its first at src[s]
+  __shared__ u32 cum[GH_MAX_SOURCES + 1], src[GH_MAX_SOURCES], below_s;
   const u32 tid = threadIdx.x;
   const u32 width = 1u << low;
   const u32 bucket = blockIdx.x, bk = bucket < nbk ? bucket : nbk;
   for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
-  __syncthreads();
-  const u64 base = (u64)bucket << low;
-  u32 below = 0;  // values of all senders in lower buckets
-  for (u32 s = 0; s < sources; s++) {
-    const u32 *st = starts + (size_t)s * (nbk + 1);
-    const u32 first = st[0];
-    below += st[bk] - first;
-    if (bucket >= nbk) continue;
-    const u32 lo = word_off[s] + (st[bucket] - first), hi = word_off[s] + (st[bucket + 1] - first);
-    for (u32 i0 = lo + tid; i0 < hi; i0 += 8 * GH_THREADS) {
-      u32 g[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const u32 i = i0 + k * GH_THREADS;
-        g[k] = i < hi ? (u32)words[i] : 0xFFFFFFFFu;
+  {
+    // one thread per sender (GH_THREADS >= GH_MAX_SOURCES): its words in this bucket and in the buckets below
+    u32 mine = 0, lower = 0;
+    if (tid < sources) {
+      const u32 *st = starts + (size_t)tid * (nbk + 1);
+      const u32 first = st[0];
+      lower = st[bk] - first;
+      if (bucket < nbk) {
+        mine = st[bucket + 1] - st[bucket];
+        src[tid] = word_off[tid] + (st[bucket] - first);
       }
-#pragma unroll
-      for (int k = 0; k < 8; k++)
-        if (g[k] != 0xFFFFFFFFu && base + g[k] <= m) atomicAdd(&hist[gh_slot(g[k])], 1u);  // fillers (above m) are skipped
     }
+    u32 all_mine, all_lower;
+    const u32 incl = block_scan_incl<OpSum>(mine, scan_s, &all_mine);
+    if (tid < sources) cum[tid + 1] = incl;
+    if (tid == 0) cum[0] = 0;
+    __syncthreads();
+    block_scan_incl<OpSum>(lower, scan_s, &all_lower);
+    if (tid == 0) below_s = all_lower;
+    __syncthreads();
+  }
+  const u64 base = (u64)bucket << low;
+  const u32 below = below_s, total = cum[sources];
+  for (u32 x0 = tid; x0 < total; x0 += 8 * GH_THREADS) {
+    u32 g[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 x = x0 + k * GH_THREADS;
+      g[k] = 0xFFFFFFFFu;
+      if (x < total) {
+        u32 lo = 0, hi = sources;  // the sender whose range holds x
+        while (hi - lo > 1) {
+          const u32 mid = (lo + hi) / 2;
+          if (cum[mid] <= x) lo = mid;
+          else hi = mid;
+        }
+        g[k] = (u32)words[src[lo] + (x - cum[lo])];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (g[k] != 0xFFFFFFFFu && base + g[k] <= m) atomicAdd(&hist[gh_slot(g[k])], 1u);  // fillers (above m) are skipped
   }
   __syncthreads();
   const u32 per = (width + GH_THREADS - 1) / GH_THREADS;
@@ -456,6 +481,7 @@ void gap_group16(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *start) {
 
 void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32 *starts, u32 sources, u32 nbk, u64 m, u32 *S) {
   const u32 n_buckets = (u32)((m >> GH_LOW_MAX) + 1);
+  if (sources < 1 || sources > GH_MAX_SOURCES) fail(BWT_HIP_EINVAL, "grouped prefix: 1..%u senders", GH_MAX_SOURCES);
   if (n_buckets != nbk && n_buckets != nbk + 1) fail(BWT_HIP_EINTERNAL, "grouped prefix: %u buckets for %lu gap indices", nbk, (unsigned long)(m + 1));
   KernelTimer kt(c, "gap:k_bucket_prefix", (double)(m + 1) * 4);
   hipLaunchKernelGGL(k_bucket_prefix16_multi, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, words, word_off, starts, sources, nbk,
