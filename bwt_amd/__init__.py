@@ -77,7 +77,10 @@ def lib():
         "bwt_hip_dist_wire_unpack": [vp, vp, i64, vp],
         "bwt_hip_dist_merge_slice": [vp, vp, i64, vp, i64, vp, vp, vp],
         "bwt_hip_dist_merge_slice_noalloc": [vp, vp, i64, vp, i64, vp, vp, vp],
-        "bwt_hip_dist_samples_route": [vp, i32, vp, vp, i64, i64, i64, i64, i64, i32, vp, vp, _i64p],
+        "bwt_hip_dist_samples_route": [vp, i32, vp, vp, i64, i64, i64, i64, i64, i32, i32, vp, vp, _i64p],
+        "bwt_hip_dist_layout": [vp, i64, i32, _i64p, C.POINTER(i32)],
+        "bwt_hip_dist_chains_grouped": [vp, vp, i64, i64, i64, vp, vp, i64, vp, _i64p, _i64p, _i64p],
+        "bwt_hip_dist_merge_slice_grouped": [vp, vp, i64, vp, i64, vp, _i64p, vp, i32, i64, vp, vp],
         "bwt_hip_dist_samples_answer": [vp, vp, i64, i64, vp, i64, i64, i64, vp, vp],
         "bwt_hip_dist_samples_place": [vp, i32, vp, vp, i64, vp, vp, i64, i64, i64, i64, i64, vp, vp, _i64p],
         "bwt_hip_set_timing": [vp, i32],
@@ -371,12 +374,32 @@ class Context:
         _chk(lib().bwt_hip_dist_merge_slice_noalloc(self._h, C.c_void_p(lL_ptr), mL, C.c_void_p(rL_ptr), rn, C.c_void_p(g_ptr),
                                                     C.c_void_p(out_ptr), C.c_void_p(S_ptr)))
 
-    def dist_samples_route(self, is_left, rank_ptr, pos_ptr, n, a, c, m, r, members, queries_ptr, perm_ptr):
+    def dist_samples_route(self, is_left, rank_ptr, pos_ptr, n, a, c, m, r, members, shift, queries_ptr, perm_ptr):
         vp = C.c_void_p
         counts = np.zeros(members, dtype=np.int64)
-        _chk(lib().bwt_hip_dist_samples_route(self._h, int(is_left), vp(rank_ptr), vp(pos_ptr), n, a, c, m, r, members,
+        _chk(lib().bwt_hip_dist_samples_route(self._h, int(is_left), vp(rank_ptr), vp(pos_ptr), n, a, c, m, r, members, shift,
                                               vp(queries_ptr), vp(perm_ptr), _p(counts, _i64p)))
         return counts
+
+    def dist_layout(self, m, parts):
+        """(first left rank of every part [parts + 1 entries], shift): shift 13 = the merge's g values travel grouped"""
+        lo = np.zeros(parts + 1, dtype=np.int64)
+        shift = C.c_int(0)
+        _chk(lib().bwt_hip_dist_layout(self._h, m, parts, _p(lo, _i64p), C.byref(shift)))
+        return lo, shift.value
+
+    def dist_chains_grouped(self, l, ra, rb, build_gap_segment_sz, g_text_ptr, words_ptr, words_cap, starts_ptr):
+        vp = C.c_void_p
+        out = [C.c_int64(0) for _ in range(3)]
+        _chk(lib().bwt_hip_dist_chains_grouped(self._h, l._h, ra, rb, build_gap_segment_sz, vp(g_text_ptr), vp(words_ptr), words_cap,
+                                               vp(starts_ptr), *[C.byref(x) for x in out]))
+        return [x.value for x in out]  # words, buckets, fillers
+
+    def dist_merge_slice_grouped(self, lL_ptr, mL, rL_ptr, rn, words_ptr, word_off, starts_ptr, nbk, out_ptr, S_ptr):
+        vp = C.c_void_p
+        off = np.ascontiguousarray(word_off, dtype=np.int64)
+        _chk(lib().bwt_hip_dist_merge_slice_grouped(self._h, vp(lL_ptr), mL, vp(rL_ptr), rn, vp(words_ptr), _p(off, _i64p), vp(starts_ptr),
+                                                    len(off), nbk, vp(out_ptr), vp(S_ptr)))
 
     def dist_samples_answer(self, queries_ptr, n_left, n_right, S_ptr, i_lo, right_before, a, g_ptr, answers_ptr):
         vp = C.c_void_p

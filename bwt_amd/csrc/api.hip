@@ -810,6 +810,69 @@ int bwt_hip_dist_bounds(int64_t m, int parts, int64_t *lo) {
   API_END
 }
 
+int bwt_hip_dist_layout(bwt_hip_ctx *ctx, int64_t m, int parts, int64_t *lo, int *shift) {
+  API_BEGIN
+  need(ctx && m >= 0 && parts >= 1 && parts <= 256 && lo && shift, "ctx, m >= 0, 1 <= parts <= 256, lo, shift");
+  *shift = partition_shift(ctx->c, (u64)m);
+  partition_bounds((u64)m, (u32)parts, lo, *shift);
+  API_END
+}
+
+int bwt_hip_dist_chains_grouped(bwt_hip_ctx *ctx, bwt_hip_block *l_, int64_t ra, int64_t rb, int64_t seg, uint32_t *g_text_dev,
+                                uint16_t *words_dev, int64_t words_cap, uint32_t *starts_dev, int64_t *n_words,
+                                int64_t *n_buckets, int64_t *fillers) {
+  API_BEGIN
+  need(ctx && l_ && g_text_dev && words_dev && starts_dev && n_words && n_buckets && fillers, "ctx, l, device buffers, outputs");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  Block &l = *as_block(l_);
+  const u64 m = (u64)l.len();
+  need(gap_grouping_applies(c, m), "a left block whose g values travel grouped (bwt_hip_dist_layout: shift != 0)");
+  const u32 nb = (u32)((m >> 13) + 1);
+  *n_buckets = nb;
+  DBuf<u32> start(c, gap_group16_starts(m));
+  u64 total = 0;
+  if (rb > ra) {
+    DBuf<u32> g0;
+    ChainLayout lay = run_chains(c, l, ra, rb, seg, g0);
+    chains_text_order(c, lay, g0.get(), g_text_dev);
+    total = (u64)lay.seg * lay.n_chains;
+    need((i64)total <= words_cap, "words_cap >= the positions rounded up to whole chains");
+    DBuf<u32> g1(c, (size_t)total);
+    gap_group16(c, g0.get(), g1.get(), total, m, start.get());
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, start.get() + nb, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    *n_words = (i64)c.h_scalars[0];
+    if (*n_words > 0) HIP_CHECK(hipMemcpyAsync(words_dev, g0.get(), (size_t)*n_words * 2, hipMemcpyDeviceToDevice, c.stream));
+  } else {
+    HIP_CHECK(hipMemsetAsync(start.get(), 0, gap_group16_starts(m) * sizeof(u32), c.stream));
+    *n_words = 0;
+  }
+  HIP_CHECK(hipMemcpyAsync(starts_dev, start.get(), ((size_t)nb + 1) * sizeof(u32), hipMemcpyDeviceToDevice, c.stream));
+  // fillers (value m + 1) inside the buckets 0 .. nb-1: all of them, or none when m + 1 opens a bucket of its own
+  *fillers = (((m + 1) >> 13) < nb) ? (i64)total - (rb - ra) : 0;
+  c.sync();
+  API_END
+}
+
+int bwt_hip_dist_merge_slice_grouped(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
+                                     const uint16_t *words_dev, const int64_t *word_off, const uint32_t *starts_dev, int sources,
+                                     int64_t nbk, uint8_t *out_dev, uint32_t *S_dev) {
+  API_BEGIN
+  need(ctx && S_dev && mL >= 0 && rn >= 0 && word_off && starts_dev && sources >= 1 && sources <= 256 && nbk >= 0, "ctx, S_dev, mL >= 0, rn >= 0, word_off, starts_dev, 1 <= sources <= 256");
+  need((mL == 0 || lL_dev) && (rn == 0 || (rL_dev && words_dev)) && (mL + rn == 0 || out_dev), "device buffers");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  std::vector<u32> h_off((size_t)sources);
+  for (int s = 0; s < sources; s++) h_off[(size_t)s] = (u32)word_off[s];
+  DBuf<u32> d_off(c, (size_t)sources);
+  HIP_CHECK(hipMemcpyAsync(d_off.get(), h_off.data(), (size_t)sources * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+  gap_prefix_grouped(c, words_dev, d_off.get(), starts_dev, (u32)sources, (u32)nbk, (u64)mL, S_dev);
+  merge_symbols(c, lL_dev, (u64)mL, rL_dev, (u64)rn, S_dev, out_dev);
+  c.sync();
+  API_END
+}
+
 int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l_, int64_t ra, int64_t rb, int64_t seg, uint32_t *g_dev) {
   API_BEGIN
   need(ctx && l_ && g_dev, "ctx, l, g_dev");
@@ -899,14 +962,15 @@ int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
 }
 
 int bwt_hip_dist_samples_route(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
-                               int64_t a, int64_t cpos, int64_t m, int64_t r, int members, uint32_t *queries_dev,
+                               int64_t a, int64_t cpos, int64_t m, int64_t r, int members, int shift, uint32_t *queries_dev,
                                uint32_t *perm_dev, int64_t *counts) {
   API_BEGIN
   need(ctx && counts && n >= 0 && members >= 1 && members <= 256, "ctx, counts, n >= 0, 1 <= members <= 256");
   need(n == 0 || (queries_dev && (is_left ? (rank_dev && perm_dev) : pos_dev != nullptr)), "device buffers");
   Ctx &c = ctx->c;
   HIP_CHECK(hipSetDevice(c.device));
-  if (is_left) samples_route_left(c, rank_dev, (u64)n, a, (u64)m, (u32)members, queries_dev, perm_dev, counts);
+  need(shift == 0 || shift == 13, "shift as bwt_hip_dist_layout gives it");
+  if (is_left) samples_route_left(c, rank_dev, (u64)n, a, (u64)m, (u32)members, queries_dev, perm_dev, counts, shift);
   else samples_route_right(c, pos_dev, (u64)n, cpos, (u64)r, (u32)members, queries_dev, counts);
   API_END
 }

@@ -15,7 +15,7 @@ samples of its own text range, and a merge of two such blocks (reference include
 
 Exchanged per merge and GPU: the left L in (m bytes, or m/4 when the text's symbols span at most four values and
 L crosses the links as two bits per symbol), about 4r/G bytes of g values and r/G (or r/4G) bytes of right symbols
-through the all-to-alls, 8 bytes per sample.  The result is the same block the
+through the all-to-alls (half of that where the g values travel grouped, see dist_merge), 8 bytes per sample.  The result is the same block the
 single-GPU recursion builds: L bit for bit (the slices concatenated), and the same samples, because the same tree is
 merged with the same rules.
 
@@ -175,14 +175,39 @@ class HipDistOps:
         self.ctx.dist_merge_slice(lL.data_ptr(), mL, rL.data_ptr(), rn, g_rel.data_ptr(), out.data_ptr(), S.data_ptr())
         return out, S
 
-    def samples_route(self, is_left, rank, pos, a, c, m, r, members):
+    def samples_route(self, is_left, rank, pos, a, c, m, r, members, shift):
         n = int(pos.numel())
         queries = self.empty(n, self.torch.int32)
         perm = self.empty(n if is_left else 0, self.torch.int32)
         self._ready()
-        counts = self.ctx.dist_samples_route(is_left, rank.data_ptr(), pos.data_ptr(), n, a, c, m, r, members,
+        counts = self.ctx.dist_samples_route(is_left, rank.data_ptr(), pos.data_ptr(), n, a, c, m, r, members, shift,
                                              queries.data_ptr(), perm.data_ptr())
         return queries, perm, [int(x) for x in counts]
+
+    def layout(self, m, parts):
+        return self.ctx.dist_layout(m, parts)
+
+    def chains_grouped(self, lb, p_lo, p_hi):
+        """(g in text order, 16-bit words grouped by gap bucket, bucket bounds [buckets + 1], buckets, fillers among the words)"""
+        cnt = p_hi - p_lo
+        seg = self.seg if self.seg > 0 else 1024
+        cap = cnt + seg
+        m = lb.b - lb.a
+        g = self.empty(cnt, self.torch.int32)
+        words = self.empty(cap, self.torch.int16)
+        starts = self.empty((m >> 13) + 2, self.torch.int32)
+        self._ready()
+        n_words, nb, fillers = self.ctx.dist_chains_grouped(lb, p_lo, p_hi, self.seg, g.data_ptr(), words.data_ptr(), cap, starts.data_ptr())
+        return g, words[:n_words], starts[:nb + 1], nb, fillers
+
+    def merge_slice_grouped(self, lL, rL, words, word_off, starts, nbk):
+        mL, rn = int(lL.numel()), int(rL.numel())
+        out = self.empty(mL + rn, self.torch.uint8)
+        S = self.empty(mL + 1, self.torch.int32)
+        self._ready()
+        self.ctx.dist_merge_slice_grouped(lL.data_ptr(), mL, rL.data_ptr(), rn, words.data_ptr(), word_off, starts.data_ptr(), nbk,
+                                          out.data_ptr(), S.data_ptr())
+        return out, S
 
     def samples_answer(self, queries, n_left, n_right, S, i_lo, right_before, a, g):
         out = self.empty(n_left + n_right, self.torch.int32)
@@ -261,16 +286,40 @@ def dist_merge(ops, comm, blk, ns_req):
             fullL[s_rank_l - a] = 0
     lb = ops.left_block(a, c, fullL, s_rank_l, e_rank_l)
 
+    # Where the gap histogram groups its values in two passes (left blocks of 2^21 suffixes and more) the g values
+    # travel grouped: the sender groups the values of its own chains by gap bucket and sends each part the 16-bit
+    # words of the part's buckets plus the buckets' bounds -- half the bytes of the values; parts then begin at
+    # multiples of 8192 left ranks (shift 13).
+    lo, shift = ops.layout(m, G)
+    lo = [int(x) for x in lo]
+
     # 2. LF chains of this GPU's share of the right positions
     p_lo, p_hi = c + k * r // G, c + (k + 1) * r // G
-    g = ops.chains(lb, p_lo, p_hi)
-    ops.free_block(lb)
+    if not shift:
+        g = ops.chains(lb, p_lo, p_hi)
+        ops.free_block(lb)
 
-    # 3. every g value to the GPU that owns its part; then the right symbols each part interleaves
-    g_parts, counts = ops.partition(g, m, G)
-    table = comm.all_gather_i64(counts)  # table[src][part]
-    g_in = comm.all_to_all(g_parts, counts, [table[s][k] for s in range(G)])
-    R = [sum(table[s][d] for s in range(G)) for d in range(G)]  # right suffixes per part
+        # 3. every g value to the GPU that owns its part; then the right symbols each part interleaves
+        g_parts, counts = ops.partition(g, m, G)
+        table = comm.all_gather_i64(counts)  # table[src][part]
+        g_in = comm.all_to_all(g_parts, counts, [table[s][k] for s in range(G)])
+        R = [sum(table[s][d] for s in range(G)) for d in range(G)]  # right suffixes per part
+    else:
+        g, words, starts, nb, fillers = ops.chains_grouped(lb, p_lo, p_hi)
+        ops.free_block(lb)
+        B = [min(x >> shift, nb) for x in lo[:G]] + [nb]  # part d owns the buckets B[d] .. B[d+1]-1
+        at = [int(x) for x in starts[torch.tensor(B, dtype=torch.int64, device=starts.device)].cpu().tolist()]
+        wcount = [at[d + 1] - at[d] for d in range(G)]
+        table = comm.all_gather_i64(wcount + [fillers])  # table[src][part]; [src][G] = the sender's fillers, all in the last part
+        # (as bytes: the transports carry no 16-bit integers)
+        w_in = comm.all_to_all(words[:at[G]].view(torch.uint8), [2 * x for x in wcount], [2 * table[s][k] for s in range(G)],
+                               pad=16).view(torch.int16)
+        nbk = B[k + 1] - B[k]
+        st_out = torch.cat([starts[B[d]:B[d + 1] + 1] for d in range(G)])
+        st_in = comm.all_to_all(st_out, [B[d + 1] - B[d] + 1 for d in range(G)], [nbk + 1] * G)
+        R = [sum(table[s][d] for s in range(G)) for d in range(G)]
+        R[G - 1] -= sum(table[s][G] for s in range(G))
+        word_off = [sum(table[s][k] for s in range(j)) for j in range(G)]
     rb = [0]
     for x in R:
         rb.append(rb[-1] + x)
@@ -306,17 +355,19 @@ def dist_merge(ops, comm, blk, ns_req):
             at_s += recv_splits[d]
 
     # 4. this part's slice of the merged block
-    lo = [int(x) for x in dist_bounds(m, G)]
     i_lo = min(lo[k], m)
     i_hi = min(lo[k + 1], m)
-    out, S = ops.merge_slice(fullL[i_lo:i_hi], rL, g_in)
+    if not shift:
+        out, S = ops.merge_slice(fullL[i_lo:i_hi], rL, g_in)
+    else:
+        out, S = ops.merge_slice_grouped(fullL[i_lo:i_hi], rL, w_in, word_off, st_in, nbk)
     sizes = [min(lo[d + 1], m) - min(lo[d], m) + R[d] for d in range(G)]
 
     # 5. the samples stay with their holders: requests out, answers back, every holder thins its own
     held = [meta[j][4] for j in range(G)]
     n_all, first_index = sum(held), sum(held[:k])
     ns_out = min(ns_req, m + r)
-    queries, perm, ask = ops.samples_route(k < q, blk.samp_rank, blk.samp_pos, a, c, m, r, G)
+    queries, perm, ask = ops.samples_route(k < q, blk.samp_rank, blk.samp_pos, a, c, m, r, G, shift)
     asked = comm.all_gather_i64(ask)  # asked[src][member]
     incoming = [asked[j][k] for j in range(G)]
     q_in = comm.all_to_all(queries, ask, incoming)

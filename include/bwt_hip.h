@@ -196,6 +196,29 @@ int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l, bwt_hip_block *r, int64_t bu
 
 /* lo[0..parts]: first left rank (equally: first g value) of every part; lo[parts] = m + 1. */
 int bwt_hip_dist_bounds(int64_t m, int parts, int64_t *lo);
+/* The same bounds as the context's GPU would cut them, and *shift: 0, or 13 for left blocks whose g values travel
+   GROUPED (those of 2^21 suffixes and more, where the gap histogram groups its values in two passes): parts then
+   begin at multiples of 2^shift left ranks, part(v) = ((v >> shift) * scale) >> 32, and the merge's steps are
+   bwt_hip_dist_chains_grouped and bwt_hip_dist_merge_slice_grouped instead of dist_chains + dist_partition and
+   dist_merge_slice.  All processes of a merge get the same answer (it depends on m only). */
+int bwt_hip_dist_layout(bwt_hip_ctx *ctx, int64_t m, int parts, int64_t *lo, int *shift);
+/* dist_chains plus the grouping of the values on the sending side: g_text_dev as dist_chains' g_dev; words_dev
+   receives the values' low 13 bits as 16-bit words grouped by bucket = value >> 13 (any order inside a bucket),
+   starts_dev[k] = first word of bucket k for k in [0, *n_buckets], *n_buckets = (m >> 13) + 1, *n_words = their number.
+   The words of part d are those of its buckets [lo[d] >> 13, lo[d+1] >> 13) (the last part: up to *n_buckets); they and
+   the matching stretch of starts_dev (one entry more than buckets) are what travels.  The last chain, if short, is
+   filled up with the value m + 1: *fillers of those lie in the last bucket sent (the receiver skips them: they are
+   above its last gap index) and have to be taken off the last part's count of right suffixes.  words_cap: capacity of
+   words_dev in words, at least rb - ra rounded up to whole chains. */
+int bwt_hip_dist_chains_grouped(bwt_hip_ctx *ctx, bwt_hip_block *l, int64_t ra, int64_t rb, int64_t build_gap_segment_sz,
+                                uint32_t *g_text_dev, uint16_t *words_dev, int64_t words_cap, uint32_t *starts_dev,
+                                int64_t *n_words, int64_t *n_buckets, int64_t *fillers);
+/* dist_merge_slice from grouped values: sender s's words for this part lie at words_dev[word_off[s] ...) with the
+   bounds of the part's nbk buckets at starts_dev[s * (nbk + 1) ...] (as the sender's starts_dev held them: only
+   differences are used). */
+int bwt_hip_dist_merge_slice_grouped(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
+                                     const uint16_t *words_dev, const int64_t *word_off, const uint32_t *starts_dev, int sources,
+                                     int64_t nbk, uint8_t *out_dev, uint32_t *S_dev);
 /* g_dev[j - ra] = number of suffixes of block l smaller than T[j:], for the positions j in [ra, rb), ra >= l.b
    (the block needs L, s_rank, e_rank only: one imported with n_samples = 0 will do). */
 int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l, int64_t ra, int64_t rb, int64_t build_gap_segment_sz,
@@ -237,7 +260,8 @@ int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
    by position; the processes in order hold the block's samples in order; ranks are block-relative + the block's
    first position, 32-bit words).  In a merge of [a,c) and [c,b) over `members` processes a holder asks, per sample,
    the process that knows the number its new rank needs:
-   route   is_left: queries_dev[x] = left rank - first left rank of the part that owns it, grouped by part, and
+   route   is_left: queries_dev[x] = left rank - first left rank of the part that owns it (parts as bwt_hip_dist_layout
+           cuts them: its shift), grouped by part, and
            perm_dev[x] = the sample the request belongs to; otherwise queries_dev[i] = pos[i] - first position of the
            member whose chains cover pos[i] (member d covers [c + d*r/members, c + (d+1)*r/members)), which are grouped
            already.  counts[d] = requests for member d.
@@ -249,7 +273,7 @@ int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
            has index first_index + i among the n_all samples of both blocks; the kept ones (the reference's thinning
            to ssa_n_samples_out) go to o_rank_dev / o_pos_dev in order, *kept of them.  With null outputs only *kept. */
 int bwt_hip_dist_samples_route(bwt_hip_ctx *ctx, int is_left, const uint32_t *rank_dev, const uint32_t *pos_dev, int64_t n,
-                               int64_t a, int64_t c, int64_t m, int64_t r, int members, uint32_t *queries_dev,
+                               int64_t a, int64_t c, int64_t m, int64_t r, int members, int shift, uint32_t *queries_dev,
                                uint32_t *perm_dev, int64_t *counts);
 int bwt_hip_dist_samples_answer(bwt_hip_ctx *ctx, const uint32_t *queries_dev, int64_t n_left, int64_t n_right,
                                 const uint32_t *S_dev, int64_t i_lo, int64_t right_before, int64_t a, const uint32_t *g_dev,

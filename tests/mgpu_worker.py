@@ -119,9 +119,50 @@ class NumpyDistOps:
         return self.torch.from_numpy(g.view(np.int32).copy())
 
     @staticmethod
-    def bounds(m, parts):
-        scale = (parts << 32) // (m + 1)
-        return [((k << 32) + scale - 1) // scale for k in range(parts)] + [m + 1], scale
+    def shift_of(m):
+        """13 where the g values of a merge travel grouped by gap bucket: left blocks whose gap indices 0..m need 9 to
+        18 bits above the 13 a bucket spans (include/bwt_hip.h, bwt_hip_dist_layout)."""
+        return 13 if 8 < (m + 1).bit_length() - 13 <= 18 else 0
+
+    @classmethod
+    def bounds(cls, m, parts, shift=0):
+        scale = (parts << 32) // ((m >> shift) + 1)
+        return [(((k << 32) + scale - 1) // scale) << shift for k in range(parts)] + [m + 1], scale
+
+    def layout(self, m, parts):
+        shift = self.shift_of(m)
+        return self.bounds(m, parts, shift)[0], shift
+
+    def chains_grouped(self, lb, p_lo, p_hi):
+        """bwt_hip_dist_chains_grouped restated: the values' low 13 bits grouped by bucket (here in descending order
+        inside a bucket: any order is allowed), bucket bounds, and a few fillers m + 1 as a short last chain leaves them."""
+        a, c = lb
+        m = c - a
+        g = self.chains(lb, p_lo, p_hi)
+        v = self._ints(g)
+        nb = (m >> 13) + 1
+        n_fill = 5 if len(v) else 0
+        allv = np.concatenate([v, np.full(n_fill, m + 1, dtype=np.int64)])
+        order = np.lexsort((-allv, allv >> 13))
+        allv = allv[order]
+        starts = np.searchsorted(allv >> 13, np.arange(nb + 1), side="left")
+        n_words = int(starts[nb])
+        fillers = n_fill if ((m + 1) >> 13) < nb else 0
+        words = self.torch.from_numpy((allv[:n_words] & 8191).astype(np.uint16).view(np.int16).copy())
+        return g, words, self._words(starts), nb, fillers
+
+    def merge_slice_grouped(self, lL, rL, words, word_off, starts, nbk):
+        mL = int(lL.numel())
+        w = words.numpy().view(np.uint16).astype(np.int64)
+        st = self._ints(starts).reshape(len(word_off), nbk + 1)
+        vals = []
+        for s_, off in enumerate(word_off):
+            for b in range(nbk):
+                lo_, hi_ = off + st[s_][b] - st[s_][0], off + st[s_][b + 1] - st[s_][0]
+                vals.append(w[lo_:hi_] + (b << 13))
+        g = np.concatenate(vals) if vals else np.zeros(0, dtype=np.int64)
+        g = g[g <= mL]  # fillers lie above the part's last gap index
+        return self.merge_slice(lL, rL, self._words(g))
 
     def partition(self, g, m, parts):
         lo, scale = self.bounds(m, parts)
@@ -146,11 +187,11 @@ class NumpyDistOps:
         return self.torch.from_numpy(out), self.torch.from_numpy(S.astype(np.uint32).view(np.int32).copy())
 
     # the three sample steps as include/bwt_hip.h defines them (bwt_hip_dist_samples_route / _answer / _place)
-    def samples_route(self, is_left, rank, pos, a, c, m, r, members):
+    def samples_route(self, is_left, rank, pos, a, c, m, r, members, shift):
         if is_left:
-            lo, scale = self.bounds(m, members)
+            lo, scale = self.bounds(m, members, shift)
             rk = self._ints(rank) - a
-            part = ((rk.astype(np.uint64) * np.uint64(scale)) >> np.uint64(32)).astype(np.int64)
+            part = (((rk >> shift).astype(np.uint64) * np.uint64(scale)) >> np.uint64(32)).astype(np.int64)
             order = np.argsort(part, kind="stable")[::-1].copy()   # any order inside a part is allowed: a reversed one
             order = order[np.argsort(part[order], kind="stable")]
             queries = rk[order] - np.array(lo, dtype=np.int64)[part[order]]

@@ -100,3 +100,23 @@ def test_gloo_distributed_merge_with_numpy_parts(tmp_path, world, lpr, direct, s
     r, p = ob.samples()
     assert (res["rank"] == r).all() and (res["pos"] == p).all()
     assert int(res["sizes"].sum()) == n and len(res["sizes"]) == world
+
+
+def test_gloo_distributed_merge_with_grouped_g_exchange(tmp_path):
+    """A left block of 2^21 suffixes and more: the g values travel grouped by gap bucket (16-bit words + bucket bounds,
+    parts cut at multiples of 8192 left ranks; include/bwt_hip.h, bwt_hip_dist_layout / _chains_grouped /
+    _merge_slice_grouped), restated in numpy with a descending order inside the buckets and a few fillers."""
+    n, ns, seg, world = 4200100, 3000, 1000, 2
+    out = str(tmp_path / "res.npz")
+    _launch(world, ["--ops", "oracle", "--algo", "dist", "--text_len", str(n), "--lpr", "1", "--ns", str(ns), "--seg", str(seg),
+                    "--direct", "1"], out, timeout=600)
+    res = np.load(out)
+    T = gen_text(n, 42, 4)
+    th = multi_gpu.leaf_threshold(n, world)
+    o = Oracle.opt(n, alpha_min=1, alpha_max=4, bwt_rec_threshold=th, ssa_n_samples=ns, build_gap_segment_sz=seg)
+    ob = Oracle.pmbwt(T, o)
+    assert (res["L"] == ob.L).all()
+    assert (int(res["s_rank"]), int(res["e_rank"])) == (ob.s_rank, ob.e_rank)
+    r, p = ob.samples()
+    assert (res["rank"] == r).all() and (res["pos"] == p).all()
+    assert res["sizes"][0] % 8192 != 0 and int(res["sizes"].sum()) == n  # (the cut is at a multiple of 8192 LEFT ranks)
