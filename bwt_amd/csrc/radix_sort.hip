@@ -144,13 +144,12 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
 
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
 // rounds, 2 gap histogram), so that a profiler lists their launches apart.
-// DB: digit bits (8, or 9 where two wider passes replace three)
+// DB: digit bits (8; 9 where two wider passes replace three; 10 for the second pass of lean windows above 2^31 suffixes)
 template <class K, int USE, bool TEXT, int DB = 8>
 __global__ void __launch_bounds__(RH_THREADS)
     k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk,
               TextKeys tk, const uint2 *__restrict__ tmap = nullptr) {
   constexpr int DIG = 1 << DB;
-  static_assert(DIG <= RH_THREADS, "one thread per digit adds the rows up");
   __shared__ u32 cnt[RH_THREADS / 64][DIG];  // one row of LDS counters per wave
   __shared__ u32 stage[TEXT ? TK_STAGE_WORDS : 1];
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -169,11 +168,11 @@ __global__ void __launch_bounds__(RH_THREADS)
       if (tile0 + tid * RH_ITEMS + r < n) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
-    if (tid < (u32)DIG) {
+    for (u32 d = tid; d < (u32)DIG; d += RH_THREADS) {
       u32 tot = 0;
 #pragma unroll
-      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-      counts[(size_t)tid * nblk + (nblk - 1 - tile)] = tot;  // tiles in reverse: this pass is reverse-stable
+      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][d];
+      counts[(size_t)d * nblk + (nblk - 1 - tile)] = tot;  // tiles in reverse: this pass is reverse-stable
     }
     return;
   }
@@ -192,11 +191,11 @@ __global__ void __launch_bounds__(RH_THREADS)
       if ((u32)r * RH_THREADS + tid < tm.y) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
-    if (tid < (u32)DIG) {
+    for (u32 d = tid; d < (u32)DIG; d += RH_THREADS) {
       u32 tot = 0;
 #pragma unroll
-      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-      counts[(size_t)tid * nblk + tile] = tot;
+      for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][d];
+      counts[(size_t)d * nblk + tile] = tot;
     }
     return;
   }
@@ -232,11 +231,11 @@ __global__ void __launch_bounds__(RH_THREADS)
     if (valid) atomicAdd(&cnt[w][d], 1u);  // LDS counter of this wave; order is irrelevant for a count
   }
   __syncthreads();
-  if (tid < (u32)DIG) {
+  for (u32 d = tid; d < (u32)DIG; d += RH_THREADS) {
     u32 tot = 0;
 #pragma unroll
-    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][tid];
-    counts[(size_t)tid * nblk + tile] = tot;
+    for (int k = 0; k < RH_THREADS / 64; k++) tot += cnt[k][d];
+    counts[(size_t)d * nblk + tile] = tot;
   }
 }
 
@@ -1110,8 +1109,8 @@ void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 
 
 int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs) {
   const int bbits = text.b1 + text.b2;
-  if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 9 || text.pbits < 13 + text.b1 || text.pbits > 31 ||
-      n >= (1ull << 31) || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
+  if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 10 || text.pbits < 13 + text.b1 || text.pbits > 32 ||
+      n >= (1ull << 32) - 8 || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
       64 - text.b2 - text.lean_deep < text.pbits + text.vbits || text.K0 * text.w < bbits + text.lean_deep || text.K0 * text.w > 56)
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad lean layout (b1 %d, b2 %d, deep %d, pbits %d, vbits %d, K0 %d, w %d, n %zu)", text.b1,
          text.b2, text.lean_deep, text.pbits, text.vbits, text.K0, text.w, n);
@@ -1129,7 +1128,7 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   }
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
   if (count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
-  DBuf<u32> counts(c, (size_t)512 * nblk2);
+  DBuf<u32> counts(c, (size_t)(text.b2 > 9 ? 1024 : 512) * nblk2);
   DBuf<u32> tfirst(c, nd1 + 1);
   DBuf<uint2> tmap(c, nblk2);
   if (text.b1 > 8) lean_text_pass<9>(c, elems[1], n, nblk, first, count_keys, counts.get());
@@ -1137,7 +1136,8 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)n, tfirst.get(),
                      tmap.get(), nblk2);
   HIP_CHECK(hipGetLastError());
-  if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
+  if (text.b2 > 9) lean_second_pass<10>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
+  else if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
   else lean_second_pass<8>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), digits.get());
   bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
   u32 *d_max = c.d_scalars + 12;

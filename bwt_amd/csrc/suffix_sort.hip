@@ -1703,22 +1703,23 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   return 1;
 }
 
-// Lean bucket route: windows of up to 2^31 suffixes of small symbols (DNA), 8-byte elements with nothing on the
+// Lean bucket route: windows of up to 2^32 - 9 suffixes of small symbols (DNA), 8-byte elements with nothing on the
 // side (TextKeys::lean).  Two radix passes -- the text pass on the lower b1 bucket bits, which it does not store,
 // the second on the top b2 -- leave 2^(b1+b2) buckets of a few thousand suffixes; k_bucket_emit orders a bucket in
 // LDS on the next 16 key bits, settles what those leave tied on the key bits below them and only then on the
 // text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing usable was written.
 static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
-  if (N < c.bucket_min_n || N < 2 || N >= (1ull << 31)) return 0;
+  if (N < c.bucket_min_n || N < 2 || N >= (1ull << 32) - 8) return 0;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
   const int one_based = pow2 ? 0 : 1;
   const int w = bits_for((u64)(span + one_based));
   // buckets of 4100 to 8200 suffixes (the largest bucket of a random text then stays below the 9216 a workgroup holds)
+  // (2^19 buckets for windows of 2^31 suffixes and more: a 10-bit second digit)
   int bbits = 16;
-  while (bbits < 18 && (N >> bbits) > 8200) bbits++;
-  if (c.wide_bbits >= 2 && c.wide_bbits <= 18) bbits = c.wide_bbits;
+  while (bbits < 19 && (N >> bbits) > 8200) bbits++;
+  if (c.wide_bbits >= 2 && c.wide_bbits <= 19) bbits = c.wide_bbits;
   if ((N >> bbits) > 8200) return 0;
-  const int b2 = bbits > 16 ? 9 : (bbits + 1) / 2, b1 = bbits - b2;
+  const int b2 = bbits > 18 ? 10 : (bbits > 16 ? 9 : (bbits + 1) / 2), b1 = bbits - b2;
   const int vbits = c.sym_bits;
   int pbits = bits_for(N - 1);
   if (pbits < 13 + b1) pbits = 13 + b1;
@@ -1797,7 +1798,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
   // a text with long repeats goes straight to the plain passes and the refinement rounds
   const bool repeats = window_has_long_repeats(c, a, N);
-  // Large windows: lean elements up to 2^31 suffixes, wide ones beyond.  These routes settle every tie on the text
+  // Large windows: lean elements; wide ones where those do not apply.  These routes settle every tie on the text
   // itself, so they sort the leaf's own suffixes and no window slack.  (force_wide 3: never the lean route; windows
   // the packed elements can index then take those elements' own bucket route, the lean route's predecessor.)
   const u64 NL = (u64)(b - a);

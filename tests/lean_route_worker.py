@@ -58,10 +58,20 @@ def main():
     same_as_oracle(ctx, T, 4, 80000, 900)
     T = gen_repetitive(3000, 60, 0.001, seed=43, sigma=4)
     same_as_oracle(ctx, T, 4, 70000, 1000)
-    # 2e7 suffixes with 16, 17 and 18 bucket bits (8- and 9-bit digits) against the packed route of a plain context
+    # 19 bucket bits (the 10-bit second digit of windows of 2^31 suffixes and more) on a small text, against the oracle
+    ctx.close()
+    os.environ["BWT_HIP_WIDE_BBITS"] = "19"
+    ctx = bwt_amd.Context(0)
+    ctx.set_timing(2)
+    T = gen_text(400000, 31, 4)
+    for th in (len(T), 130000):
+        same_as_oracle(ctx, T, 4, th, 2500)
+    assert lean_launches(ctx) == 1 + 4, sorted(ctx.timers())
+    same_as_oracle(ctx, gen_text(300000, 32, 7), 7, 300000, 900)
+    # 2e7 suffixes with 16 to 19 bucket bits (8-, 9- and 10-bit digits) against the packed route of a plain context
     n = 20000000
     res = []
-    for bb in ("16", "17", "18"):
+    for bb in ("16", "17", "18", "19"):
         ctx.close()
         os.environ["BWT_HIP_WIDE_BBITS"] = bb
         ctx = bwt_amd.Context(0)

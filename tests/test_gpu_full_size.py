@@ -165,9 +165,24 @@ def test_n3_1e9_two_leaves_lean_route(ctx):
     ctx.trim()
 
 
-def test_n3_1e9_one_leaf_wide_route(ctx):
-    """3.1e9 suffixes as one leaf (more than 2^31: the wide bucket route, 8 + 1 byte elements, 2^19 buckets): the
-    same L as the two-leaf build, decoded back to the text on the device."""
+def _forced_wide_context():
+    """A second context on the same GPU whose large windows take the wide route (8 + 1 byte elements)."""
+    import bwt_amd
+    old = os.environ.get("BWT_HIP_FORCE_WIDE")
+    os.environ["BWT_HIP_FORCE_WIDE"] = "1"
+    try:
+        return bwt_amd.Context(0)
+    finally:
+        if old is None:
+            del os.environ["BWT_HIP_FORCE_WIDE"]
+        else:
+            os.environ["BWT_HIP_FORCE_WIDE"] = old
+
+
+def test_n3_1e9_one_leaf(ctx):
+    """3.1e9 suffixes as one leaf (more than 2^31: lean elements with 32-bit positions, 2^19 buckets through a 10-bit
+    second digit): decoded back to the text on the device; the same L as the two-leaf build, and as the wide route
+    (8 + 1 byte elements, three passes) that a second context is made to take."""
     n = 3100000000
     ctx.set_timing(2)
     ctx.reset_timers()
@@ -175,13 +190,27 @@ def test_n3_1e9_one_leaf_wide_route(ctx):
     one = ctx.pmbwt(n, 38750000)
     got = variants(ctx)
     ctx.set_timing(0)
-    assert same_variants(got, ["leaf:bucket_emit_items=7,wide"]), got
+    assert same_variants(got, ["leaf:bucket_emit_items=7,lean"]), got
     assert one.ibwt_mismatches() == 0
-    f1 = h8(one.L)
+    f1, info1 = h8(one.L), (one.s_rank, one.e_rank)
+    r1, p1 = one.samples()
     one.free()
     two = ctx.pmbwt(n // 2, 38750000)
     assert h8(two.L) == f1
     two.free()
+    ctx.trim()
+    wide = _forced_wide_context()
+    try:
+        wide.set_timing(2)
+        wide.gen_text(n, 42, 4)
+        w = wide.pmbwt(n, 38750000)
+        assert same_variants(variants(wide), ["leaf:bucket_emit_items=7,wide"]), variants(wide)
+        assert h8(w.L) == f1 and (w.s_rank, w.e_rank) == info1
+        r2, p2 = w.samples()
+        assert (r2 == r1).all() and (p2 == p1).all()
+        w.free()
+    finally:
+        wide.close()
     ctx.trim()
 
 
