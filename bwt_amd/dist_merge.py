@@ -7,7 +7,7 @@ samples of its own text range, and a merge of two such blocks (reference include
   1. the left block's L is sent to every GPU of the group (point-to-point, all links at once); each builds the left
      rank structure; 2. the right block's text positions are split evenly and every GPU runs the LF chains of its share
      (g_j = number of left suffixes below T[j:] depends on the left block and the text only, and the text is on every
-     GPU); 3. the merge is cut by left rank into 2q parts (bwt_hip_dist_bounds): an all-to-all moves every g value to
+     GPU); 3. the merge is cut by left rank into 2q parts (bwt_hip_dist_layout): an all-to-all moves every g value to
      the GPU that owns its part, a second one the right symbols each part interleaves; 4. every GPU builds the prefix
      sums of its part and writes its slice of the merged L; 5. the samples do not move: every GPU keeps those of its
      own text range, asks the GPU that knows for the number each new rank needs (the part's prefix sums for a left
@@ -23,8 +23,6 @@ torch is plumbing: tensors are buffers, torch.distributed is the transport (back
 host staging in the tests).  All BWT work goes through the C-ABI (include/bwt_hip.h, bwt_hip_dist_*).
 """
 import numpy as np
-
-from . import dist_bounds
 
 
 class DistBlock:

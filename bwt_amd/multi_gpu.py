@@ -15,8 +15,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 
 def split_ranges(a, b, depth):
     """The 2^depth ranges that bwt_rec's midpoint splitting of [a,b) reaches at `depth`."""
