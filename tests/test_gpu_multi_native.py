@@ -97,3 +97,22 @@ def test_native_multi_grouped_g_exchange_boundaries(ctx, n, world):
     L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, ns, 1000)
     assert used == world and (s_rank, e_rank) == info1
     assert (L == L1).all() and (r == r1).all() and (p == p1).all()
+
+
+def test_layout_of_a_distributed_merge(ctx):
+    """bwt_hip_dist_layout: parts are contiguous and cover the gap indices 0..m; below 2^21 left suffixes they are cut
+    anywhere (shift 0, the bounds of bwt_hip_dist_bounds), from there on at multiples of 8192 (shift 13: the g values
+    travel grouped by gap bucket) and still even to within a few buckets."""
+    for m, parts in [(5, 2), (100000, 8), (2 ** 21 - 2, 4), (2 ** 21 - 1, 4), (2 ** 21 + 8191, 2), (387500000, 8), (1550000000, 8),
+                     (2 ** 31 - 2, 2), (2 ** 31 - 1, 2), (3000000000, 4)]:
+        lo, shift = ctx.dist_layout(m, parts)
+        lo = [int(x) for x in lo]
+        grouped = 2 ** 21 <= m + 1 < 2 ** 31
+        assert shift == (13 if grouped else 0), (m, shift)
+        assert lo[0] == 0 and lo[-1] == m + 1 and all(x <= y for x, y in zip(lo, lo[1:]))
+        if not grouped:
+            assert lo == [int(x) for x in bwt_amd.dist_bounds(m, parts)]
+        else:
+            assert all(x % 8192 == 0 for x in lo[:-1])
+            sizes = [min(y, m + 1) - min(x, m + 1) for x, y in zip(lo, lo[1:])]
+            assert max(sizes) - min(sizes) < 3 * 8192, (m, parts, sizes)  # whole buckets, and the last one may be short
