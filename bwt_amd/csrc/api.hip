@@ -175,7 +175,9 @@ static void adopt_text(Ctx &c, const u8 *dT, i64 n) {
 
 static void check_n(i64 n) {
   if (n < 1) fail(BWT_HIP_EINVAL, "n must be at least 1");
-  if ((u64)n > 0xFFFFFFFFull - 3) fail(BWT_HIP_EINVAL, "n = %ld exceeds 2^32 - 4", (long)n);
+  // Device indices are 32-bit words, and kernels index whole tiles (up to 16384 positions) with them: the last tile of a
+  // text that ends closer than that to 2^32 would wrap (seen in the rank structure's build at n = 2^32 - 16).
+  if ((u64)n > 0xFFFFFFFFull - 0xFFFFull) fail(BWT_HIP_EINVAL, "n = %ld exceeds 2^32 - 65536", (long)n);
 }
 
 int bwt_hip_set_text(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n) {

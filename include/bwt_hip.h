@@ -16,7 +16,7 @@
  *   - one context per (process, GPU); a context and its blocks are used by one
  *     host thread at a time, like the reference (its global `stat`, util.h:209).
  *   - the text obeys the reference's contract (README.md:66-68): T[n-1] == 0
- *     and no other 0.  n <= 2^32 - 4.
+ *     and no other 0.  n <= 2^32 - 65536.
  *   - ranks taken or returned are absolute (rank r of block [a,b) lies in
  *     [a,b)), as in the reference.
  */

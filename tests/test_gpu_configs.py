@@ -148,3 +148,14 @@ def test_binary_text_of_long_runs(ctx):
                        [np.full(150, 1, dtype=np.uint8), np.zeros(1, dtype=np.uint8)])
     _same_as_oracle(ctx, T, 2, len(T), 100)
     _same_as_oracle(ctx, T, 2, 7000, 100)
+
+
+def test_text_length_limit(ctx):
+    """Texts of up to 2^32 - 65536 symbols are taken (device indices are 32-bit words and kernels index whole tiles with
+    them); one more is refused with BWT_HIP_EINVAL before anything is allocated."""
+    import bwt_amd
+    with pytest.raises(bwt_amd.BwtHipError) as e:
+        ctx.gen_text(2 ** 32 - 65535, 1, 4)
+    assert "exceeds 2^32 - 65536" in str(e.value)
+    ctx.gen_text(1000, 1, 4)  # the context is still usable
+    assert ctx.pmbwt(1000, 10).ibwt_mismatches() == 0
