@@ -116,3 +116,29 @@ def test_layout_of_a_distributed_merge(ctx):
             assert all(x % 8192 == 0 for x in lo[:-1])
             sizes = [min(y, m + 1) - min(x, m + 1) for x, y in zip(lo, lo[1:])]
             assert max(sizes) - min(sizes) < 3 * 8192, (m, parts, sizes)  # whole buckets, and the last one may be short
+
+
+def test_rccl_transport_moves_bytes(ctx):
+    """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd through the transport's one primitive: with a single rank the
+    only peer is the rank itself, so a send and its receive in one batch move a block's L into another block's buffer."""
+    import ctypes as C
+    T = gen_text(300000, 5, 4)
+    ctx.set_text(T)
+    a, b = ctx.leaf(0, 100000, 10), ctx.leaf(100000, 200000, 10)
+    want = a.L
+    assert not (b.L == want).all()
+    t = bwt_amd.Transport.rccl(ctx, bwt_amd.Transport.rccl_unique_id(), 0, 1)
+
+    class P2P(C.Structure):  # bwt_hip_p2p
+        _fields_ = [("peer", C.c_int), ("is_send", C.c_int), ("buf", C.c_void_p), ("bytes", C.c_int64)]
+
+    class TR(C.Structure):   # bwt_hip_transport
+        _fields_ = [("self", C.c_void_p), ("rank", C.c_int), ("world", C.c_int),
+                    ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(P2P))), ("destroy", C.c_void_p)]
+    tr = C.cast(t._h, C.POINTER(TR)).contents
+    assert (tr.rank, tr.world) == (0, 1)
+    ops = (P2P * 2)(P2P(0, 1, a.L_device, 100000), P2P(0, 0, b.L_device, 100000))
+    ctx.sync()
+    assert tr.exchange(tr.self, 2, ops) == 0
+    assert (b.L == want).all()
+    t.close()
