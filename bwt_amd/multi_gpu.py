@@ -130,6 +130,64 @@ def pmbwt_tree(ops, rank, world, n, leaves_per_rank, dist, hdr_device="cpu", fre
     return blk
 
 
+def verify_against_one_gpu(ctx, held, algo, rank, world, th, ns, seg, dist, dev, coll_device=None):
+    """Builds the same tree on this rank's GPU alone and compares what the multi-GPU build left here with it: the
+    slice of L byte for byte, every sample this rank holds, the special ranks where they are known, and the number of
+    samples over all ranks.  Returns a dict for the JSON line (the same on every rank); never raises.  coll_device:
+    where the tensors of the two small collectives live (default `dev`; "cpu" under gloo)."""
+    import numpy as np
+    import torch
+    res = {"L": False, "samples": False, "special_ranks": False, "error": None}
+    n_held = 0
+    blk = None
+    try:
+        if algo == "native":
+            r, p = held.samples()
+            first, L, s_rank, e_rank = held.first, held.L, held.s_rank, held.e_rank
+        else:
+            k = held.ranks.index(rank)
+            first = int(sum(held.sizes[:k]))
+            L = held.L.cpu().numpy()
+            r = held.samp_rank.cpu().numpy().view(np.uint32).astype(np.int64)
+            p = held.samp_pos.cpu().numpy().view(np.uint32).astype(np.int64)
+            s_rank, e_rank = held.s_rank, held.e_rank
+        n_held = len(p)
+        blk = ctx.pmbwt(th, ns, seg)
+        ctx.sync()
+        m = blk.b - blk.a
+        Lt = torch.empty(m, dtype=torch.uint8, device=dev)
+        rt = torch.empty(blk.n_samples, dtype=torch.int64, device=dev)
+        pt = torch.empty(blk.n_samples, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        blk.export_device(Lt.data_ptr(), rt.data_ptr(), pt.data_ptr())
+        ctx.sync()
+        mine = Lt[first:first + len(L)].cpu().numpy()
+        res["L"] = bool(len(mine) == len(L) and np.array_equal(mine, L))
+        ra, pa = rt.cpu().numpy(), pt.cpu().numpy()
+        at = np.searchsorted(pa, p)
+        at[at >= len(pa)] = 0
+        res["samples"] = bool(len(pa) > 0 and np.all(np.diff(p) > 0) and np.array_equal(pa[at], p) and np.array_equal(ra[at], r))
+        res["special_ranks"] = bool((s_rank < 0 or s_rank == blk.s_rank) and (e_rank < 0 or e_rank == blk.e_rank))
+        res["n_samples"] = int(blk.n_samples)
+        del Lt, rt, pt
+    except Exception as e:  # reported, not raised: the timing line is still worth having
+        res["error"] = "rank %d: %r" % (rank, e)
+    if blk is not None:
+        blk.free()
+    # the ranks' findings in one place: all slices equal, all samples accounted for
+    flags = torch.tensor([int(res["L"]), int(res["samples"]), int(res["special_ranks"])], dtype=torch.int64, device=coll_device or dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    count = torch.tensor([n_held, -1 if res["error"] else 0], dtype=torch.int64, device=coll_device or dev)
+    dist.all_reduce(count, op=dist.ReduceOp.SUM)
+    out = {"L_slices_equal": bool(flags[0].item()), "samples_equal": bool(flags[1].item()),
+           "special_ranks_equal": bool(flags[2].item()), "ranks_with_errors": int(-count[1].item()), "error": res["error"],
+           "what": "after the timed steps every rank builds the same tree on its own GPU alone (bwt_hip_pmbwt) and compares its slice of L, its samples and the special ranks it knows"}
+    if "n_samples" in res:
+        out["samples_equal"] = out["samples_equal"] and int(count[0].item()) == res["n_samples"]
+        out["n_samples"] = res["n_samples"]
+    return out
+
+
 def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs.  --leaves is the leaf count of the
     whole tree (the same tree as on one GPU), so every rank builds leaves / world of them."""
@@ -216,13 +274,15 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             s = ctx.dist_pmbwt(transport, th_native, ns, args.seg)
             ctx.sync()
             return s
-    else:
+    elif algo == "tree":
         ops = HipOps(ctx, ns, args.seg, True, dev)
 
         def step():
             blk = pmbwt_tree(ops, rank, world, n, lpr, dist, hdr_device=dev)
             ctx.sync()
             return blk
+    else:
+        raise SystemExit("BWT_MGPU_ALGO=%s: native, dist or tree" % algo)
 
     for _ in range(args.warmup):
         blk = step()
@@ -247,6 +307,10 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     dt = float(dt.item()) / args.steps
     timers = ctx.timers()
     ctx.set_timing(0)
+    verified = None
+    if algo in ("native", "dist") and not os.environ.get("BWT_MGPU_NO_VERIFY"):
+        verified = verify_against_one_gpu(ctx, last.d if algo == "dist" else last, algo, rank, world,
+                                          leaf_threshold(n, total_leaves), ns, args.seg, dist, dev)
     if rank == 0:
         from bwt_amd.benchutil import phase_table, roofline
         th = leaf_threshold(n, total_leaves)
@@ -266,6 +330,8 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
                                                                         "native": "distributed merges (C++ driver, RCCL send/recv)"}.get(algo, "pairwise merge tree"))},
             # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
             "roofline": roofline(timers), "cpu_baseline": None, "schedule": algo, "native_transport_fallback": fallback,
+            # outside the timed region: every rank's slice against the same tree built on that rank's GPU alone
+            "verified_against_one_gpu": verified,
             "phases_rank0": phase_table(timers, args.steps),
         }
     if last is not None:

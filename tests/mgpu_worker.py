@@ -301,6 +301,15 @@ def main():
         staging = not args.direct
         dist_merge.warm_groups(dist, groups, rank, world, dev, staging)
         blk = dist_merge.pmbwt_dist(ops, rank, world, args.n, args.lpr, dist, groups, dev, staging)
+        if args.ops == "hip":
+            # what bench.py's N > 1 leg reports as verified_against_one_gpu: true here, false for a slice with one byte changed
+            v = multi_gpu.verify_against_one_gpu(ctx, blk, "dist", rank, world, th, args.ns, args.seg, dist, dev, coll_device="cpu")
+            assert v["L_slices_equal"] and v["samples_equal"] and v["special_ranks_equal"] and not v["ranks_with_errors"], v
+            bad = dist_merge.DistBlock(blk.a, blk.b, blk.ranks, blk.sizes, blk.L.clone(), blk.s_rank, blk.e_rank, blk.samp_rank, blk.samp_pos)
+            if rank == world - 1:
+                bad.L[bad.L.numel() // 2] ^= 1
+            v = multi_gpu.verify_against_one_gpu(ctx, bad, "dist", rank, world, th, args.ns, args.seg, dist, dev, coll_device="cpu")
+            assert not v["L_slices_equal"] and v["samples_equal"], v
         L = dist_merge.gather_L(blk, rank, world, dist, dev, staging)
         samples = dist_merge.gather_samples(blk, rank, world, dist, dev, staging)
         if rank == 0:

@@ -60,3 +60,23 @@ def test_distributed_merge_equals_single_process(ctx, tmp_path, world, lpr, n, s
     r, p = ref.samples()
     assert (res["rank"] == r).all() and (res["pos"] == p).all()
     assert int(res["sizes"].sum()) == n and len(res["sizes"]) == world
+
+
+@pytest.mark.parametrize("algo", ["native", "dist"])
+def test_bench_multi_gpu_leg_on_one_rank(algo):
+    """bench.py's N > 1 leg, rehearsed with one rank: the JSON line, the schedule it names, and its own check of the
+    result against a build on the rank's GPU alone."""
+    import json
+    env = dict(os.environ, BWT_BENCH_FORCE_DIST="1", BWT_MGPU_ALGO=algo, MASTER_PORT="29531")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "3000001", "--leaves", "4", "--steps", "1",
+                        "--warmup", "1", "--cpu_n", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT,
+                       env=env, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["schedule"] == algo and line["native_transport_fallback"] is None
+    v = line["verified_against_one_gpu"]
+    assert v["L_slices_equal"] and v["samples_equal"] and v["special_ranks_equal"], v
+    assert v["ranks_with_errors"] == 0 and v["error"] is None and v["n_samples"] > 0
+    assert line["n_gpus"] == 1 and line["config"]["leaves"] == 4 and line["value"] > 0
