@@ -105,10 +105,10 @@ def _build(c, n, leaves, ns):
     return blk, L, r, p, info
 
 
-def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves):
+def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves, sigma=4):
     ctx.set_timing(2)
     ctx.reset_timers()
-    ctx.gen_text(n, 42, 4)
+    ctx.gen_text(n, 42, sigma)
     blk, L, r, p, info = _build(ctx, n, leaves, ns)
     got = variants(ctx)
     ctx.set_timing(0)
@@ -130,7 +130,7 @@ def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves):
     plain = _plain_route_context(n)
     try:
         plain.set_timing(2)
-        plain.gen_text(n, 42, 4)
+        plain.gen_text(n, 42, sigma)
         b2, L2, r2, p2, info2 = _build(plain, n, leaves, ns)
         assert launches(plain, "leaf:k_bucket_emit") == 0
         assert info2 == info and (r2 == r).all() and (p2 == p).all()
@@ -162,6 +162,13 @@ def test_n3_1e9_two_leaves_lean_route(ctx):
     """bench.py's default on one GPU: 3.1e9 symbols as two leaves of 1.55e9 suffixes (more than 2^29: the lean
     bucket route, 2^18 buckets) and one merge; against the same tree sorted as (key, position) pairs."""
     _full_size(ctx, 3100000000, 2, 38750000, ["leaf:bucket_emit_items=7,lean"], 8)
+    ctx.trim()
+
+
+def test_config5_bytes_n1e9_two_leaves(ctx):
+    """Config 5: a byte alphabet (255 symbols, two 16-ary wavelet levels) at n = 1e9, two leaves and one merge; both
+    leaves on the lean bucket route, against the same tree sorted as (key, position) pairs."""
+    _full_size(ctx, 10 ** 9, 2, 12500000, ["leaf:bucket_emit_items=8,lean"], 4, sigma=255)
     ctx.trim()
 
 
