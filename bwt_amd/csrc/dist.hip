@@ -151,10 +151,15 @@ __global__ void k_wire_unpack2(const u8 *__restrict__ packed, u8 *__restrict__ d
     __builtin_memcpy(&w, packed + (s0 >> 2), 8);  // 32 + 6 bits are needed; the caller pads the stream by 8 bytes
     const u32 bits = (u32)(w >> (2 * (s0 & 3)));
     u32 o[4];
+    // min_sym + code modulo 256 in every byte: the terminator travels as code (0 - min_sym) mod 4, which with min_sym
+    // above 252 sums to 256 and more, and a plain 32-bit sum would carry that into the neighbouring symbol.  The low
+    // seven bits are added (3 + 127 carries nowhere), the top bit by exclusive or.
+    const u32 M = min_sym * 0x01010101u;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const u32 b = (bits >> (8 * q)) & 255u;
-      o[q] = ((b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | ((b >> 6) << 24)) + min_sym * 0x01010101u;
+      const u32 codes = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | ((b >> 6) << 24);
+      o[q] = (codes + (M & 0x7F7F7F7Fu)) ^ (M & 0x80808080u);
     }
     *reinterpret_cast<uint4 *>(dst + s0) = make_uint4(o[0], o[1], o[2], o[3]);
   } else {

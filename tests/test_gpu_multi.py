@@ -80,3 +80,54 @@ def test_bench_multi_gpu_leg_on_one_rank(algo):
     assert v["L_slices_equal"] and v["samples_equal"] and v["special_ranks_equal"], v
     assert v["ranks_with_errors"] == 0 and v["error"] is None and v["n_samples"] > 0
     assert line["n_gpus"] == 1 and line["config"]["leaves"] == 4 and line["value"] > 0
+
+
+@pytest.mark.parametrize("base,sigma", [(1, 4), (100, 3), (252, 4), (253, 2), (253, 3), (254, 2)])
+def test_wire_codec_with_the_terminator_inside(ctx, base, sigma):
+    """Two bits per symbol between GPUs: every symbol comes back as it went, at any offset and length, also next to
+    the terminator (which has no code of its own and is put back by the receiver) and for alphabets that end at 255,
+    where symbol + 3 does not fit a byte.  Device buffers: the L arrays of uploaded blocks."""
+    from bwt_amd import dist_merge
+    n = 70000
+    T = gen_text(n, 13, sigma)
+    T[:-1] += base - 1
+    ctx.set_text(T)
+    assert ctx.dist_wire_packable()
+    two = np.array([0, 1], dtype=np.int64)
+
+    def device_bytes(a):
+        return ctx.upload_block(0, len(a), a, 0, 0, two, two)
+
+    for count, off, z in ((n - 500, 0, 17), (n - 501, 0, 31), (4099, 3, 4098), (4099, 5, 0), (50001, 1, 25000), (15, 0, 7), (33, 2, 16), (16, 0, 15)):
+        src = T[off:off + count].copy()
+        src[z] = 0
+        s = device_bytes(np.concatenate([np.zeros(off, dtype=np.uint8), src]))
+        packed = device_bytes(np.zeros(dist_merge.wire_bytes(count) + 64, dtype=np.uint8))
+        out = device_bytes(np.full(off + count + 64, 77, dtype=np.uint8))
+        ctx.dist_wire_pack(s.L_device + off, count, packed.L_device)
+        ctx.dist_wire_unpack(packed.L_device, count, out.L_device + off)
+        ctx.sync()
+        got = out.L
+        for blk in (s, packed, out):
+            blk.free()
+        assert (got[:off] == 77).all() and (got[off + count:] == 77).all()
+        got = got[off:off + count]
+        keep = np.arange(count) != z
+        assert (got[keep] == src[keep]).all(), (base, sigma, count, off, z, np.nonzero(got != src)[0][:8])
+
+
+@pytest.mark.parametrize("base,sigma", [(253, 2), (252, 4), (254, 2), (253, 3)])
+def test_native_multi_alphabets_that_end_at_255(base, sigma):
+    """Merges whose left block is spread over several ranks, on alphabets at the top of the byte range."""
+    import bwt_amd
+    from oracle import Oracle
+    n = 8438
+    T = gen_text(n, 21, sigma)
+    T[:-1] += base - 1
+    for world, th in ((4, 2110), (8, 1055)):
+        L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, 40, 7)
+        o = Oracle.opt(n, alpha_min=base, alpha_max=base + sigma - 1, bwt_rec_threshold=th, ssa_n_samples=40, build_gap_segment_sz=7)
+        ob = Oracle.pmbwt(T, o)
+        assert (L == ob.L).all() and (s_rank, e_rank) == (ob.s_rank, ob.e_rank)
+        orr, op = ob.samples()
+        assert (r == orr).all() and (p == op).all()

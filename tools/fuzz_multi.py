@@ -20,6 +20,8 @@ def make(rng):
         n = int(rng.choice([rng.integers(40, 600), rng.integers(600, 9000), rng.integers(9000, 400000)]))
     sigma = int(rng.choice([2, 3, 4, 4, 4, 4, 5, 16, 200]))
     base = int(rng.integers(1, 256 - sigma + 1)) if rng.random() < 0.4 else 1
+    if rng.random() < 0.1:
+        base = 256 - sigma  # the alphabet ends at 255: symbol + 3 does not fit a byte
     if rng.random() < 0.2 and not big:
         body = np.where(rng.random(n - 1) < 0.9, 0, rng.integers(0, sigma, size=n - 1))  # skewed: parts of very different sizes
     else:
