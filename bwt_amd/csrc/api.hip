@@ -94,6 +94,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_XFER_CHUNK")) c.xfer_chunk = atoll(v);
   if (const char *v = getenv("BWT_HIP_DEFER_CHAINS")) c.defer_chains = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current
   *out = h.release();
   API_END
@@ -152,6 +153,10 @@ void bwt_hip_host_free(void *p) {
 }
 
 static void drop_text(Ctx &c) {
+  if (c.runs) c.release(c.runs);
+  c.runs = nullptr;
+  c.n_runs = 0;
+  c.runs_valid = false;
   if (c.T_owned) c.release(c.T_owned);
   c.T_owned = nullptr;
   c.T = nullptr;

@@ -45,11 +45,33 @@ struct ChainParams {
   // second launch: SA[rank] of the left block (samples as inverse.hip's RankIndex holds them)
   const u32 *samp_bits, *by_rank, *by_rank_pos;
   u32 ns;
+  // long runs of one symbol in T, by position: n_runs starts, then n_runs ends (exclusive); suffix_less steps over them
+  const u32 *runs;
+  u32 n_runs;
 };
+
+// end of the listed run that x lies strictly inside (its first position is below x, so T[x-1] is the run's symbol
+// too), 0 if there is none
+__device__ __forceinline__ u64 run_end_inside(const u32 *__restrict__ runs, u32 n_runs, u64 x) {
+  u32 lo = 0, hi = n_runs;  // the last run that starts below x
+  while (lo < hi) {
+    const u32 mid = (lo + hi) / 2;
+    if ((u64)runs[mid] < x) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo == 0) return 0;
+  const u64 end = runs[n_runs + lo - 1];
+  return x < end ? end : 0;
+}
 
 // T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop).  Eight symbols per (unaligned) load
 // while both suffixes have eight left: on repetitive texts these comparisons run for thousands of symbols.
-__device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64 x, u64 y) {
+// Runs of one symbol (the N of an assembly's gaps, millions long) would make them run for the length of the run,
+// once per position of the run: after 256 equal symbols that are all one value, the comparison looks both positions
+// up in the list of long runs and, where both lie inside one, steps to the end of the shorter remainder.
+__device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64 x, u64 y, const u32 *__restrict__ runs,
+                                            u32 n_runs) {
+  u32 since = 0;
   while (x + 8 <= n && y + 8 <= n) {
     u64 wx, wy;
     __builtin_memcpy(&wx, T + x, 8);
@@ -60,6 +82,19 @@ __device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64
     }
     x += 8;
     y += 8;
+    if (n_runs && ++since >= 32) {
+      since = 0;
+      if (wx == (wx & 0xFFull) * 0x0101010101010101ull) {
+        // T[x-1] = T[y-1] = that value: a run that x (y) lies strictly inside continues with it
+        const u64 ex = run_end_inside(runs, n_runs, x);
+        const u64 ey = ex ? run_end_inside(runs, n_runs, y) : 0;
+        if (ex && ey) {
+          const u64 skip = ex - x < ey - y ? ex - x : ey - y;
+          x += skip;
+          y += skip;
+        }
+      }
+    }
   }
   for (;; x++, y++) {
     u32 cx = T[x], cy = T[y];
@@ -112,7 +147,7 @@ __device__ __forceinline__ u64 chain_interval(const ChainParams &P, const u32 *b
     u32 klo = wm_lf(P.wm, base_s, c, lo);
     u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
     if (c == e_char && khi >= e_rank) {
-      if (suffix_less(T, P.n, P.lb - 1, j)) {
+      if (suffix_less(T, P.n, P.lb - 1, j, P.runs, P.n_runs)) {
         klo += (klo >= e_rank);
         khi += 1;
       }
@@ -168,7 +203,7 @@ __device__ __forceinline__ void chain_walk(const ChainParams &P, const u32 *base
     u32 kk = wm_lf(P.wm, base_s, sym ? sym : P.wm.min_sym, g);
     if (act) {
       if (sym == e_char && kk >= e_rank) {
-        if (suffix_less(T, P.n, P.lb - 1, j0 - step)) kk++;
+        if (suffix_less(T, P.n, P.lb - 1, j0 - step, P.runs, P.n_runs)) kk++;
       }
       g = kk;
     }
@@ -216,7 +251,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains_deferred(ChainParams P
   while (lo < hi) {
     const u32 mid = lo + (hi - lo) / 2;
     const u64 p = left_sa(P, base_s, mid);
-    if (suffix_less(P.T, P.n, p + len, j0 + len)) lo = mid + 1;
+    if (suffix_less(P.T, P.n, p + len, j0 + len, P.runs, P.n_runs)) lo = mid + 1;
     else hi = mid;
   }
   chain_walk(P, base_s, text, chain, begin, j0, lo);
@@ -489,6 +524,85 @@ void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32
   HIP_CHECK(hipGetLastError());
 }
 
+// ----------------------------------------------------------------------------
+// The list of long runs: every maximal run of one symbol that holds a whole aligned stretch of RUN_BLOCK symbols
+// (so every run of 2 * RUN_BLOCK - 1 symbols and more, and some shorter ones).  One pass over the text marks the
+// uniform stretches; the host joins neighbouring ones of one symbol; a thread per run end finds where the run
+// really begins and ends (fewer than RUN_BLOCK steps: the stretch next to it is not uniform).
+// ----------------------------------------------------------------------------
+constexpr u32 RUN_BLOCK = 4096;
+constexpr u32 RUN_MAX = 1u << 16;  // listed runs at most (the list only saves work: a run that is not on it is read)
+
+__global__ void __launch_bounds__(256) k_uniform_blocks(const u8 *__restrict__ T, u32 n_blocks, u8 *__restrict__ flags) {
+  __shared__ u32 differs;
+  const u64 base = (u64)blockIdx.x * RUN_BLOCK;
+  if (threadIdx.x == 0) differs = 0;
+  __syncthreads();
+  const u32 s = T[base];
+  const u32 pat = s * 0x01010101u;
+  const uint4 v = *reinterpret_cast<const uint4 *>(T + base + threadIdx.x * 16);  // T is 16-byte aligned
+  if ((v.x ^ pat) | (v.y ^ pat) | (v.z ^ pat) | (v.w ^ pat)) differs = 1;  // (every writer stores the same value)
+  __syncthreads();
+  if (threadIdx.x == 0) flags[blockIdx.x] = differs ? (u8)0 : (u8)s;
+}
+
+// runs[i] / runs[count + i]: on entry the first position of run i's first uniform stretch / one past its last
+__global__ void k_extend_runs(const u8 *__restrict__ T, u64 n, u32 count, u32 *__restrict__ runs) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * count) return;
+  if (t < count) {
+    u64 p = runs[t];
+    const u8 s = T[p];
+    while (p > 0 && T[p - 1] == s) p--;
+    runs[t] = (u32)p;
+  } else {
+    u64 p = runs[t];
+    const u8 s = T[p - 1];
+    while (p < n && T[p] == s) p++;
+    runs[t] = (u32)p;
+  }
+}
+
+static void ensure_run_table(Ctx &c) {
+  if (c.runs_valid) return;
+  if (c.runs) c.release(c.runs);
+  c.runs = nullptr;
+  c.n_runs = 0;
+  c.runs_valid = true;
+  const u32 n_blocks = (u32)((u64)c.n / RUN_BLOCK);
+  if (!c.run_table || n_blocks == 0) return;
+  Phase ph(c, "gap_run_table", (double)c.n);
+  DBuf<u8> flags(c, n_blocks);
+  hipLaunchKernelGGL(k_uniform_blocks, dim3(n_blocks), dim3(256), 0, c.stream, c.T, n_blocks, flags.get());
+  HIP_CHECK(hipGetLastError());
+  std::vector<u8> h(n_blocks);
+  HIP_CHECK(hipMemcpyAsync(h.data(), flags.get(), n_blocks, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  std::vector<u32> first, last;  // uniform stretches of one symbol, joined
+  for (u32 i = 0; i < n_blocks;) {
+    if (!h[i]) {
+      i++;
+      continue;
+    }
+    u32 j = i + 1;
+    while (j < n_blocks && h[j] == h[i]) j++;
+    if (first.size() < RUN_MAX) {
+      first.push_back(i * RUN_BLOCK);
+      last.push_back(j * RUN_BLOCK);  // (n <= 2^32 - 65536: no wrap)
+    }
+    i = j;
+  }
+  const u32 count = (u32)first.size();
+  if (count == 0) return;
+  first.insert(first.end(), last.begin(), last.end());
+  c.runs = (u32 *)c.alloc((size_t)count * 2 * sizeof(u32));
+  HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 2 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(k_extend_runs, dim3(ceil_div(2 * count, 64)), dim3(64), 0, c.stream, c.T, (u64)c.n, count, c.runs);
+  HIP_CHECK(hipGetLastError());
+  c.sync();  // `first` is on the stack
+  c.n_runs = count;
+}
+
 // LF-mapping chains of the right positions [ra, rb) against the block l (ra >= l.b; the positions need
 // not belong to one block: g depends on l and the text only).  g0 receives seg * n_chains values in
 // step-major order, fillers (m + 1) in the tail of a short last chain.
@@ -498,6 +612,7 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
          (long)l.a, (long)l.b);
   build_wavelet(c, l);
   c.wait_text((u64)c.n);  // the chains' suffix comparisons may read to the end of the text
+  ensure_run_table(c);
   const u64 m = (u64)l.len(), rn = (u64)(rb - ra);
   if (m + rn >= (1ull << 32) - 2) fail(BWT_HIP_EINVAL, "merged block of %lu symbols exceeds 2^32-3", (unsigned long)(m + rn));
   ChainLayout lay;
@@ -541,6 +656,8 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
   P.defer_count = d_count;
   P.samp_bits = P.by_rank = P.by_rank_pos = nullptr;
   P.ns = 0;
+  P.runs = c.runs;
+  P.n_runs = c.n_runs;
   if (l.n_samp > 0 && c.defer_chains) {
     defer_list = DBuf<u32>(c, lay.n_chains);
     P.defer_list = defer_list.get();

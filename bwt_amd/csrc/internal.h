@@ -120,6 +120,12 @@ struct Ctx {
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
   // the left block's suffix array (gap.hip); off: they restart from further and further right instead
   bool defer_chains = true;
+  // Long runs of one symbol in T (every run that holds a whole aligned 4096-symbol stretch), found on the first merge
+  // of a text: the chains' suffix comparisons step over them (gap.hip).  n_runs starts, then n_runs ends (exclusive).
+  u32 *runs = nullptr;
+  u32 n_runs = 0;
+  bool runs_valid = false;
+  bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
   bool repeat_probe = true;
   std::vector<PhaseTimer> timers;

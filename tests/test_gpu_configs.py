@@ -1,5 +1,6 @@
 """GPU parity on the other benchmark configurations and on edge cases of the path: highly repetitive text (long
 LCPs: dense ties, doubling rounds, window growth), byte alphabet (4 wavelet levels), tiny and degenerate texts."""
+import os
 import time
 
 import numpy as np
@@ -159,3 +160,67 @@ def test_text_length_limit(ctx):
     assert "exceeds 2^32 - 65536" in str(e.value)
     ctx.gen_text(1000, 1, 4)  # the context is still usable
     assert ctx.pmbwt(1000, 10).ibwt_mismatches() == 0
+
+
+def _with_runs(n, runs, seed=5, sigma=4):
+    """Random text with runs planted: (start, length, symbol)."""
+    rng = np.random.default_rng(seed)
+    T = rng.integers(1, sigma + 1, size=n, dtype=np.uint8)
+    for at, length, sym in runs:
+        T[at:at + length] = sym
+    T[-1] = 0
+    return T
+
+
+@pytest.mark.parametrize("th", [20000, 10000, 6000])
+def test_runs_of_one_symbol_across_block_boundaries(ctx, th):
+    """Runs of one symbol of more than 8191 symbols (an assembly's gaps) that cross the boundary between merged blocks,
+    plus runs of the same symbol on either side: the chains' suffix comparisons step over listed runs instead of
+    reading them.  Against the oracle."""
+    n = 40000
+    T = _with_runs(n, [(14000, 13000, 5), (1500, 9000, 5), (29000, 10500, 3)])
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    _same_as_oracle(ctx, T, 5, th, 300, 64)
+    assert "gap_run_table" in ctx.timers()
+    ctx.set_timing(0)
+    # the same runs of the largest and of the smallest symbol, and a run that ends the text
+    T = _with_runs(n, [(14000, 13000, 4), (1000, 9500, 1), (n - 9001, 9000, 1)])
+    _same_as_oracle(ctx, T, 4, th, 300)
+
+
+def test_long_runs_with_and_without_the_run_table(ctx):
+    """A 4e5-symbol run across the middle of a 3e6-symbol text: the same block with the list of runs and, in a second
+    context, with comparisons that read every symbol; decoded back on the device."""
+    import bwt_amd
+    n = 3000000
+    T = _with_runs(n, [(n // 2 - 130000, 400000, 5), (200000, 70000, 5), (2500000, 50000, 5), (2700000, 20000, 2)])
+    ctx.set_text(T)
+    t0 = time.perf_counter()
+    blk = ctx.pmbwt(n // 2 + 1, 30000)
+    L, (r, p), info = blk.L, blk.samples(), (blk.s_rank, blk.e_rank)
+    dt = time.perf_counter() - t0
+    assert blk.ibwt_mismatches() == 0
+    blk.free()
+    b4 = ctx.pmbwt(n // 4 + 1, 30000)
+    assert (b4.L == L).all()
+    b4.free()
+    old = os.environ.get("BWT_HIP_RUN_TABLE")
+    os.environ["BWT_HIP_RUN_TABLE"] = "0"
+    try:
+        plain = bwt_amd.Context(0)
+    finally:
+        if old is None:
+            del os.environ["BWT_HIP_RUN_TABLE"]
+        else:
+            os.environ["BWT_HIP_RUN_TABLE"] = old
+    try:
+        plain.set_text(T)
+        b2 = plain.pmbwt(n // 2 + 1, 30000)
+        assert (b2.L == L).all() and (b2.s_rank, b2.e_rank) == info
+        r2, p2 = b2.samples()
+        assert (r2 == r).all() and (p2 == p).all()
+        b2.free()
+    finally:
+        plain.close()
+    assert dt < 2.0, dt  # seconds; reading the runs symbol by symbol takes many times that
