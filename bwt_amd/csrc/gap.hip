@@ -571,7 +571,7 @@ static void ensure_run_table(Ctx &c) {
   c.runs_valid = true;
   const u32 n_blocks = (u32)((u64)c.n / RUN_BLOCK);
   if (!c.run_table || n_blocks == 0) return;
-  Phase ph(c, "gap_run_table", (double)c.n);
+  Phase ph(c, "gap:run_table", (double)c.n);  // (named like a kernel: once per text, not a call of a merge's phases)
   DBuf<u8> flags(c, n_blocks);
   hipLaunchKernelGGL(k_uniform_blocks, dim3(n_blocks), dim3(256), 0, c.stream, c.T, n_blocks, flags.get());
   HIP_CHECK(hipGetLastError());

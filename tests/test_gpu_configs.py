@@ -182,7 +182,7 @@ def test_runs_of_one_symbol_across_block_boundaries(ctx, th):
     ctx.set_timing(2)
     ctx.reset_timers()
     _same_as_oracle(ctx, T, 5, th, 300, 64)
-    assert "gap_run_table" in ctx.timers()
+    assert "gap:run_table" in ctx.timers()
     ctx.set_timing(0)
     # the same runs of the largest and of the smallest symbol, and a run that ends the text
     T = _with_runs(n, [(14000, 13000, 4), (1000, 9500, 1), (n - 9001, 9000, 1)])

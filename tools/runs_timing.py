@@ -1,6 +1,6 @@
 """How long texts with very long runs of one symbol take (genome assemblies hold runs of N of 1e7 symbols and more): a
 random DNA text with one run planted in it, cut into leaves so that the run crosses a leaf boundary, built, decoded
-back on the device, and timed.  Test infrastructure: python tools/runs_timing.py [n] [run] [leaves]"""
+back on the device, and timed.  Test infrastructure: python tools/runs_timing.py [n] [run] [leaves] [further runs]"""
 import os
 import sys
 import time
@@ -19,6 +19,11 @@ def main():
     T = rng.integers(1, 5, size=n, dtype=np.uint8)
     at = n // 2 - run // 3  # the run crosses the middle of the text
     T[at:at + run] = 5
+    more = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # further runs of the same symbol, 1e4 symbols up to `run`, anywhere
+    for _ in range(more):
+        length = int(10 ** rng.uniform(4, np.log10(run)))
+        where = int(rng.integers(0, n - length - 1))
+        T[where:where + length] = 5
     T[-1] = 0
     ctx = bwt_amd.Context(0)
     ctx.set_text(T)
