@@ -45,30 +45,37 @@ struct ChainParams {
   // second launch: SA[rank] of the left block (samples as inverse.hip's RankIndex holds them)
   const u32 *samp_bits, *by_rank, *by_rank_pos;
   u32 ns;
-  // long runs of one symbol in T, by position: n_runs starts, then n_runs ends (exclusive); suffix_less steps over them
+  // long stretches of a short period in T (runs of one symbol: period 1), by position: n_runs starts, ends (exclusive)
+  // and periods; suffix_less steps over them
   const u32 *runs;
   u32 n_runs;
 };
 
-// end of the listed run that x lies strictly inside (its first position is below x, so T[x-1] is the run's symbol
-// too), 0 if there is none
-__device__ __forceinline__ u64 run_end_inside(const u32 *__restrict__ runs, u32 n_runs, u64 x) {
-  u32 lo = 0, hi = n_runs;  // the last run that starts below x
+// The listed stretch (start, end, period p: T[j] = T[j-p] for start + p <= j < end) that holds x with at least its
+// period behind x inside it: *end_out and the period, 0 if there is none.  runs: n_runs starts, ends, periods.
+constexpr u32 RUN_PERIOD_MAX = 8;
+__device__ __forceinline__ u32 run_around(const u32 *__restrict__ runs, u32 n_runs, u64 x, u64 *end_out) {
+  if (x < RUN_PERIOD_MAX) return 0;
+  u32 lo = 0, hi = n_runs;  // the last stretch that starts at or below x - RUN_PERIOD_MAX
   while (lo < hi) {
     const u32 mid = (lo + hi) / 2;
-    if ((u64)runs[mid] < x) lo = mid + 1;
+    if ((u64)runs[mid] <= x - RUN_PERIOD_MAX) lo = mid + 1;
     else hi = mid;
   }
   if (lo == 0) return 0;
   const u64 end = runs[n_runs + lo - 1];
-  return x < end ? end : 0;
+  if (x >= end || x < (u64)runs[lo - 1] + RUN_PERIOD_MAX) return 0;
+  *end_out = end;
+  return runs[2 * n_runs + lo - 1];
 }
 
 // T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop).  Eight symbols per (unaligned) load
 // while both suffixes have eight left: on repetitive texts these comparisons run for thousands of symbols.
-// Runs of one symbol (the N of an assembly's gaps, millions long) would make them run for the length of the run,
-// once per position of the run: after 256 equal symbols that are all one value, the comparison looks both positions
-// up in the list of long runs and, where both lie inside one, steps to the end of the shorter remainder.
+// Runs of one symbol (the N of an assembly's gaps, millions long) and other stretches of a short period would make
+// them run for the length of the stretch, once per position of it: after every 256 equal symbols the comparison looks
+// both positions up in the list of long periodic stretches and, where both lie inside one of the same period, steps to
+// the end of the shorter remainder (the symbols behind both positions are equal and both stretches continue them by
+// the same rule, so everything stepped over is equal).
 __device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64 x, u64 y, const u32 *__restrict__ runs,
                                             u32 n_runs) {
   u32 since = 0;
@@ -84,15 +91,13 @@ __device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64
     y += 8;
     if (n_runs && ++since >= 32) {
       since = 0;
-      if (wx == (wx & 0xFFull) * 0x0101010101010101ull) {
-        // T[x-1] = T[y-1] = that value: a run that x (y) lies strictly inside continues with it
-        const u64 ex = run_end_inside(runs, n_runs, x);
-        const u64 ey = ex ? run_end_inside(runs, n_runs, y) : 0;
-        if (ex && ey) {
-          const u64 skip = ex - x < ey - y ? ex - x : ey - y;
-          x += skip;
-          y += skip;
-        }
+      u64 ex = 0, ey = 0;
+      const u32 px = run_around(runs, n_runs, x, &ex);
+      const u32 py = px ? run_around(runs, n_runs, y, &ey) : 0;
+      if (px && px == py) {
+        const u64 skip = ex - x < ey - y ? ex - x : ey - y;
+        x += skip;
+        y += skip;
       }
     }
   }
@@ -525,41 +530,59 @@ void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32
 }
 
 // ----------------------------------------------------------------------------
-// The list of long runs: every maximal run of one symbol that holds a whole aligned stretch of RUN_BLOCK symbols
-// (so every run of 2 * RUN_BLOCK - 1 symbols and more, and some shorter ones).  One pass over the text marks the
-// uniform stretches; the host joins neighbouring ones of one symbol; a thread per run end finds where the run
-// really begins and ends (fewer than RUN_BLOCK steps: the stretch next to it is not uniform).
+// The list of long periodic stretches: runs of one symbol (period 1) and repeats of a unit of up to RUN_PERIOD_MAX
+// symbols that hold a whole aligned stretch of RUN_BLOCK symbols.  One pass over the text finds, for every aligned
+// block, the smallest period p with T[i] = T[i+p] for every i of the block; the host joins neighbouring blocks of one
+// period; a thread per end extends the stretch by the same rule, RUN_BLOCK + 8 steps at most (the list only saves
+// work: a stretch listed shorter than it is, or not at all, is read symbol by symbol).
 // ----------------------------------------------------------------------------
 constexpr u32 RUN_BLOCK = 4096;
-constexpr u32 RUN_MAX = 1u << 16;  // listed runs at most (the list only saves work: a run that is not on it is read)
+constexpr u32 RUN_MAX = 1u << 16;  // listed stretches at most
 
-__global__ void __launch_bounds__(256) k_uniform_blocks(const u8 *__restrict__ T, u32 n_blocks, u8 *__restrict__ flags) {
-  __shared__ u32 differs;
+// flags[block] = smallest period 1..RUN_PERIOD_MAX of the block, 0 if it has none (the text holds 32 bytes more
+// behind the last block)
+__global__ void __launch_bounds__(256) k_periodic_blocks(const u8 *__restrict__ T, u8 *__restrict__ flags) {
+  __shared__ __align__(16) u8 sym[RUN_BLOCK + 32];
+  __shared__ u32 broken;  // bit p-1: period p does not hold
   const u64 base = (u64)blockIdx.x * RUN_BLOCK;
-  if (threadIdx.x == 0) differs = 0;
+  if (threadIdx.x == 0) broken = 0;
+  *reinterpret_cast<uint4 *>(sym + threadIdx.x * 16) = *reinterpret_cast<const uint4 *>(T + base + threadIdx.x * 16);  // T is 16-byte aligned
+  if (threadIdx.x < 2) *reinterpret_cast<uint4 *>(sym + RUN_BLOCK + threadIdx.x * 16) = *reinterpret_cast<const uint4 *>(T + base + RUN_BLOCK + threadIdx.x * 16);
   __syncthreads();
-  const u32 s = T[base];
-  const u32 pat = s * 0x01010101u;
-  const uint4 v = *reinterpret_cast<const uint4 *>(T + base + threadIdx.x * 16);  // T is 16-byte aligned
-  if ((v.x ^ pat) | (v.y ^ pat) | (v.z ^ pat) | (v.w ^ pat)) differs = 1;  // (every writer stores the same value)
+  // this thread's 16 symbols against the 16 that begin p further on: 24 bytes in three registers
+  u64 w[3];
+  __builtin_memcpy(w, sym + threadIdx.x * 16, 24);
+  u32 mine = 0;
+#pragma unroll
+  for (u32 p = 1; p < 8; p++) {
+    const u64 lo = (w[0] >> (8 * p)) | (w[1] << (64 - 8 * p)), hi = (w[1] >> (8 * p)) | (w[2] << (64 - 8 * p));
+    mine |= (u32)(lo != w[0] || hi != w[1]) << (p - 1);
+  }
+  mine |= (u32)(w[1] != w[0] || w[2] != w[1]) << 7;
+  static_assert(RUN_PERIOD_MAX == 8, "periods 1..8");
+  if (mine) atomicOr(&broken, mine);
   __syncthreads();
-  if (threadIdx.x == 0) flags[blockIdx.x] = differs ? (u8)0 : (u8)s;
+  if (threadIdx.x == 0) {
+    const u32 ok = ~broken & ((1u << RUN_PERIOD_MAX) - 1u);
+    flags[blockIdx.x] = ok ? (u8)(__ffs(ok)) : (u8)0;
+  }
 }
 
-// runs[i] / runs[count + i]: on entry the first position of run i's first uniform stretch / one past its last
+// runs[i], runs[count + i], runs[2 * count + i]: S, E, p with T[j] = T[j+p] for S <= j < E on entry; on exit the
+// stretch [start, end) that rule extends to (by at most RUN_BLOCK + 8 positions each way)
 __global__ void k_extend_runs(const u8 *__restrict__ T, u64 n, u32 count, u32 *__restrict__ runs) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * count) return;
+  const u32 i = t < count ? t : t - count;
+  const u64 p = runs[2 * count + i];
   if (t < count) {
-    u64 p = runs[t];
-    const u8 s = T[p];
-    while (p > 0 && T[p - 1] == s) p--;
-    runs[t] = (u32)p;
+    u64 s = runs[i];
+    for (u32 k = 0; k < RUN_BLOCK + 8 && s > 0 && T[s - 1] == T[s - 1 + p]; k++) s--;
+    runs[i] = (u32)s;
   } else {
-    u64 p = runs[t];
-    const u8 s = T[p - 1];
-    while (p < n && T[p] == s) p++;
-    runs[t] = (u32)p;
+    u64 e = runs[count + i];
+    for (u32 k = 0; k < RUN_BLOCK + 8 && e + p < n && T[e] == T[e + p]; k++) e++;
+    runs[count + i] = (u32)(e + p);  // T[j] = T[j-p] for start + p <= j < e + p
   }
 }
 
@@ -569,16 +592,16 @@ static void ensure_run_table(Ctx &c) {
   c.runs = nullptr;
   c.n_runs = 0;
   c.runs_valid = true;
-  const u32 n_blocks = (u32)((u64)c.n / RUN_BLOCK);
+  const u32 n_blocks = c.n > 64 ? (u32)(((u64)c.n - 64) / RUN_BLOCK) : 0;
   if (!c.run_table || n_blocks == 0) return;
   Phase ph(c, "gap:run_table", (double)c.n);  // (named like a kernel: once per text, not a call of a merge's phases)
   DBuf<u8> flags(c, n_blocks);
-  hipLaunchKernelGGL(k_uniform_blocks, dim3(n_blocks), dim3(256), 0, c.stream, c.T, n_blocks, flags.get());
+  hipLaunchKernelGGL(k_periodic_blocks, dim3(n_blocks), dim3(256), 0, c.stream, c.T, flags.get());
   HIP_CHECK(hipGetLastError());
   std::vector<u8> h(n_blocks);
   HIP_CHECK(hipMemcpyAsync(h.data(), flags.get(), n_blocks, hipMemcpyDeviceToHost, c.stream));
   c.sync();
-  std::vector<u32> first, last;  // uniform stretches of one symbol, joined
+  std::vector<u32> first, last, period;  // neighbouring blocks of one period, joined
   for (u32 i = 0; i < n_blocks;) {
     if (!h[i]) {
       i++;
@@ -589,14 +612,16 @@ static void ensure_run_table(Ctx &c) {
     if (first.size() < RUN_MAX) {
       first.push_back(i * RUN_BLOCK);
       last.push_back(j * RUN_BLOCK);  // (n <= 2^32 - 65536: no wrap)
+      period.push_back(h[i]);
     }
     i = j;
   }
   const u32 count = (u32)first.size();
   if (count == 0) return;
   first.insert(first.end(), last.begin(), last.end());
-  c.runs = (u32 *)c.alloc((size_t)count * 2 * sizeof(u32));
-  HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 2 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+  first.insert(first.end(), period.begin(), period.end());
+  c.runs = (u32 *)c.alloc((size_t)count * 3 * sizeof(u32));
+  HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 3 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
   hipLaunchKernelGGL(k_extend_runs, dim3(ceil_div(2 * count, 64)), dim3(64), 0, c.stream, c.T, (u64)c.n, count, c.runs);
   HIP_CHECK(hipGetLastError());
   c.sync();  // `first` is on the stack

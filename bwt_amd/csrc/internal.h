@@ -120,8 +120,9 @@ struct Ctx {
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
   // the left block's suffix array (gap.hip); off: they restart from further and further right instead
   bool defer_chains = true;
-  // Long runs of one symbol in T (every run that holds a whole aligned 4096-symbol stretch), found on the first merge
-  // of a text: the chains' suffix comparisons step over them (gap.hip).  n_runs starts, then n_runs ends (exclusive).
+  // Long stretches of T that repeat a unit of at most 8 symbols (runs of one symbol above all; every such stretch that
+  // holds a whole aligned 4096-symbol block), found on the first merge of a text: the chains' suffix comparisons step
+  // over them (gap.hip).  n_runs starts, then n_runs ends (exclusive), then n_runs periods.
   u32 *runs = nullptr;
   u32 n_runs = 0;
   bool runs_valid = false;

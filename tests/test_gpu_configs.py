@@ -224,3 +224,18 @@ def test_long_runs_with_and_without_the_run_table(ctx):
     finally:
         plain.close()
     assert dt < 2.0, dt  # seconds; reading the runs symbol by symbol takes many times that
+
+
+@pytest.mark.parametrize("unit", [[1, 2], [3, 1, 2], [4, 4, 1, 2, 2, 3, 1], [1, 2, 3, 4, 1, 2, 3, 3], [2, 1, 1, 3, 4, 2, 3, 1, 4]])
+def test_long_repeats_of_a_short_unit_across_block_boundaries(ctx, unit):
+    """A unit of two to nine symbols repeated over 13000 positions across the boundary between merged blocks, and again
+    elsewhere with another phase (periods up to 8 are on the list of stretches that comparisons step over; 9 is not).
+    Against the oracle."""
+    n = 40000
+    T = _with_runs(n, [])
+    u = np.array(unit, dtype=np.uint8)
+    for at, length in ((14001, 13000), (1503, 9100), (30000, 9000)):
+        T[at:at + length] = np.tile(u, length // len(u) + 1)[:length]
+    T[-1] = 0
+    _same_as_oracle(ctx, T, 4, 20000, 300, 64)
+    _same_as_oracle(ctx, T, 4, 10000, 300)

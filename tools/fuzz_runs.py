@@ -1,4 +1,4 @@
-"""Differential run of texts with long runs of one symbol: a context that steps over listed runs in the chains' suffix
+"""Differential run of texts with long runs of one symbol and long repeats of a short unit: a context that steps over listed runs in the chains' suffix
 comparisons against one that reads every symbol (BWT_HIP_RUN_TABLE=0), on random lengths, run lengths around the
 list's block size, runs next to each other, at the text's ends and across leaf boundaries.  Test infrastructure:
     python tools/fuzz_runs.py [cases] [seed]"""
@@ -32,7 +32,13 @@ def make(rng):
         at = max(0, min(at, n - 1 - length))
         if rng.random() < 0.3:
             at &= ~4095  # block-aligned starts
-        T[at:at + length] = int(rng.integers(1, sigma + 1))
+        if rng.random() < 0.5:
+            T[at:at + length] = int(rng.integers(1, sigma + 1))
+        else:  # a unit of 2 to 9 symbols repeated (the list knows periods up to 8), sometimes with one symbol changed
+            unit = rng.integers(1, sigma + 1, size=int(rng.integers(2, 10)), dtype=np.uint8)
+            T[at:at + length] = np.tile(unit, length // len(unit) + 1)[:length]
+            if rng.random() < 0.3:
+                T[at + int(rng.integers(0, length))] = int(rng.integers(1, sigma + 1))
     T[-1] = 0
     ns = int(rng.choice([2, 50, max(2, n // 50)]))
     seg = int(rng.choice([0, 0, 64, 1000]))
