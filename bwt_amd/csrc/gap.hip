@@ -207,8 +207,10 @@ __device__ __forceinline__ void chain_walk(const ChainParams &P, const u32 *base
     const u32 sym = text(act ? j0 - step : begin);
     u32 kk = wm_lf(P.wm, base_s, sym ? sym : P.wm.min_sym, g);
     if (act) {
+      // kk counts the left suffixes below T[j:] other than the block's last one, T[lb-1:], whose rank is e_rank: more
+      // than e_rank of them means that one is below T[j:] too; exactly e_rank leaves it to a comparison
       if (sym == e_char && kk >= e_rank) {
-        if (suffix_less(T, P.n, P.lb - 1, j0 - step, P.runs, P.n_runs)) kk++;
+        if (kk > e_rank || suffix_less(T, P.n, P.lb - 1, j0 - step, P.runs, P.n_runs)) kk++;
       }
       g = kk;
     }
