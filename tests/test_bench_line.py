@@ -51,8 +51,8 @@ def test_phase_table_units():
 
 
 def test_no_phase_of_a_recorded_bench_line_exceeds_the_peak():
-    """Every bench line kept under profiles/ (and the driver's BENCH_r*.json of this round on) prices its phases
-    against the 8 TB/s peak: a fraction above 1 means the byte model is not what the kernels do."""
+    """Every bench line kept under profiles/r2_bench*.json prices its phases against the 8 TB/s peak: a fraction above 1
+    means the byte model is not what the kernels do."""
     import glob
     seen = 0
     for path in glob.glob(os.path.join(ROOT, "profiles", "r2_bench*.json")):
