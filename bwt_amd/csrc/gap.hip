@@ -541,32 +541,38 @@ void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32
 constexpr u32 RUN_BLOCK = 4096;
 constexpr u32 RUN_MAX = 1u << 16;  // listed stretches at most
 
-// flags[block] = smallest period 1..RUN_PERIOD_MAX of the block, 0 if it has none (the text holds 32 bytes more
-// behind the last block)
-__global__ void __launch_bounds__(256) k_periodic_blocks(const u8 *__restrict__ T, u8 *__restrict__ flags) {
-  __shared__ __align__(16) u8 sym[RUN_BLOCK + 32];
-  __shared__ u32 broken;  // bit p-1: period p does not hold
-  const u64 base = (u64)blockIdx.x * RUN_BLOCK;
-  if (threadIdx.x == 0) broken = 0;
-  *reinterpret_cast<uint4 *>(sym + threadIdx.x * 16) = *reinterpret_cast<const uint4 *>(T + base + threadIdx.x * 16);  // T is 16-byte aligned
-  if (threadIdx.x < 2) *reinterpret_cast<uint4 *>(sym + RUN_BLOCK + threadIdx.x * 16) = *reinterpret_cast<const uint4 *>(T + base + RUN_BLOCK + threadIdx.x * 16);
-  __syncthreads();
-  // this thread's 16 symbols against the 16 that begin p further on: 24 bytes in three registers
-  u64 w[3];
-  __builtin_memcpy(w, sym + threadIdx.x * 16, 24);
-  u32 mine = 0;
+// flags[block] = smallest period 1..RUN_PERIOD_MAX of the block, 0 if it has none; *found counts the blocks that have
+// one.  A wavefront per block, 64 symbols a lane (plus the 8 behind them: the text holds 64 bytes more behind the
+// last block), nothing through LDS.
+__global__ void __launch_bounds__(256) k_periodic_blocks(const u8 *__restrict__ T, u32 n_blocks, u8 *__restrict__ flags,
+                                                         u32 *__restrict__ found) {
+  static_assert(RUN_BLOCK == 64 * 64 && RUN_PERIOD_MAX == 8, "64 lanes of 64 symbols; periods 1..8");
+  const u32 blk = blockIdx.x * 4 + (threadIdx.x >> 6);  // the same for a whole wavefront
+  if (blk >= n_blocks) return;
+  const u32 lane = threadIdx.x & 63;
+  const u8 *src = T + (u64)blk * RUN_BLOCK + lane * 64;  // T is 16-byte aligned
+  u64 w[9];
 #pragma unroll
-  for (u32 p = 1; p < 8; p++) {
-    const u64 lo = (w[0] >> (8 * p)) | (w[1] << (64 - 8 * p)), hi = (w[1] >> (8 * p)) | (w[2] << (64 - 8 * p));
-    mine |= (u32)(lo != w[0] || hi != w[1]) << (p - 1);
+  for (int q = 0; q < 4; q++) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 16);
+    w[2 * q] = (u64)v.x | ((u64)v.y << 32);
+    w[2 * q + 1] = (u64)v.z | ((u64)v.w << 32);
   }
-  mine |= (u32)(w[1] != w[0] || w[2] != w[1]) << 7;
-  static_assert(RUN_PERIOD_MAX == 8, "periods 1..8");
-  if (mine) atomicOr(&broken, mine);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u32 ok = ~broken & ((1u << RUN_PERIOD_MAX) - 1u);
-    flags[blockIdx.x] = ok ? (u8)(__ffs(ok)) : (u8)0;
+  w[8] = *reinterpret_cast<const u64 *>(src + 64);
+  u32 mine = 0;  // bit p-1: T[i] != T[i+p] for one of this lane's symbols
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int p = 1; p < 8; p++) mine |= (u32)(((w[k] >> (8 * p)) | (w[k + 1] << (64 - 8 * p))) != w[k]) << (p - 1);
+    mine |= (u32)(w[k + 1] != w[k]) << 7;
+  }
+  u32 broken = 0;
+#pragma unroll
+  for (int p = 0; p < 8; p++) broken |= (__ballot((mine >> p) & 1u) != 0ull) ? 1u << p : 0u;
+  if (lane == 0) {
+    const u32 ok = ~broken & 0xFFu;
+    flags[blk] = ok ? (u8)__ffs(ok) : (u8)0;
+    if (ok) atomicAdd(found, 1u);
   }
 }
 
@@ -598,8 +604,13 @@ static void ensure_run_table(Ctx &c) {
   if (!c.run_table || n_blocks == 0) return;
   Phase ph(c, "gap:run_table", (double)c.n);  // (named like a kernel: once per text, not a call of a merge's phases)
   DBuf<u8> flags(c, n_blocks);
-  hipLaunchKernelGGL(k_periodic_blocks, dim3(n_blocks), dim3(256), 0, c.stream, c.T, flags.get());
+  u32 *d_found = c.d_scalars + 24;
+  HIP_CHECK(hipMemsetAsync(d_found, 0, sizeof(u32), c.stream));
+  hipLaunchKernelGGL(k_periodic_blocks, dim3(ceil_div(n_blocks, 4)), dim3(256), 0, c.stream, c.T, n_blocks, flags.get(), d_found);
   HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_found, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  if (c.h_scalars[0] == 0) return;  // the usual case: nothing to list
   std::vector<u8> h(n_blocks);
   HIP_CHECK(hipMemcpyAsync(h.data(), flags.get(), n_blocks, hipMemcpyDeviceToHost, c.stream));
   c.sync();
