@@ -156,6 +156,7 @@ static void drop_text(Ctx &c) {
   if (c.runs) c.release(c.runs);
   c.runs = nullptr;
   c.n_runs = 0;
+  c.runs_host.clear();
   c.runs_valid = false;
   if (c.T_owned) c.release(c.T_owned);
   c.T_owned = nullptr;

@@ -594,11 +594,12 @@ __global__ void k_extend_runs(const u8 *__restrict__ T, u64 n, u32 count, u32 *_
   }
 }
 
-static void ensure_run_table(Ctx &c) {
+void ensure_run_table(Ctx &c) {
   if (c.runs_valid) return;
   if (c.runs) c.release(c.runs);
   c.runs = nullptr;
   c.n_runs = 0;
+  c.runs_host.clear();
   c.runs_valid = true;
   const u32 n_blocks = c.n > 64 ? (u32)(((u64)c.n - 64) / RUN_BLOCK) : 0;
   if (!c.run_table || n_blocks == 0) return;
@@ -637,8 +638,10 @@ static void ensure_run_table(Ctx &c) {
   HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 3 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
   hipLaunchKernelGGL(k_extend_runs, dim3(ceil_div(2 * count, 64)), dim3(64), 0, c.stream, c.T, (u64)c.n, count, c.runs);
   HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(first.data(), c.runs, (size_t)count * 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();  // `first` is on the stack
   c.n_runs = count;
+  c.runs_host = std::move(first);
 }
 
 // LF-mapping chains of the right positions [ra, rb) against the block l (ra >= l.b; the positions need

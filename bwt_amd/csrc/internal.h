@@ -125,6 +125,7 @@ struct Ctx {
   // over them (gap.hip).  n_runs starts, then n_runs ends (exclusive), then n_runs periods.
   u32 *runs = nullptr;
   u32 n_runs = 0;
+  std::vector<u32> runs_host;  // the same list on the host (the leaf sort sizes its window by it)
   bool runs_valid = false;
   bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
@@ -379,6 +380,8 @@ struct ChainLayout {
   u32 seg, n_chains;
 };
 ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg, DBuf<u32> &g0);
+// the list of long periodic stretches of the text (Ctx::runs), built on first use; the whole text must have arrived
+void ensure_run_table(Ctx &c);
 void chains_text_order(Ctx &c, const ChainLayout &lay, const u32 *g0, u32 *out);
 void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S);
 void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 *S, u8 *out);

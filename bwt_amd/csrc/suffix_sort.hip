@@ -1849,6 +1849,22 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   if (b < c.n) {
     slack = (b - a) / 256;
     if (slack < 4096) slack = 4096;
+    // A long periodic stretch (a run of one symbol above all) that crosses the leaf's end keeps the leaf's suffixes
+    // inside it tied until the doubling depth h exceeds half of what is left of the stretch, and a round reads ranks
+    // up to 2h beyond a suffix: the window reaches that far from the start, instead of finding out after log2 of the
+    // slack rounds, twice.  (A text that is still arriving is scanned for stretches at its first merge only.)
+    if (c.chunks.empty()) {
+      ensure_run_table(c);
+      const size_t cnt = c.n_runs;
+      for (size_t i = 0; i < cnt; i++) {
+        const i64 s0 = c.runs_host[i], e0 = c.runs_host[cnt + i];
+        if (s0 < b && e0 > b) {
+          const i64 from = s0 > a ? s0 : a;
+          const i64 want = (e0 - b) + (e0 - from) + 4096;
+          if (want > slack) slack = want;
+        }
+      }
+    }
     if (slack > c.n - b) slack = c.n - b;
   }
   for (;;) {
