@@ -13,9 +13,10 @@ leaf and each merge of the tree runs on all GPUs of its subtree (bwt_amd/dist_me
 one text.  `--leaves 8` gives the 8-leaf tree (3.875e8 suffixes per leaf, 7 merges) on any N that divides 8;
 `--n 1000000000 --leaves 2` is the one-GPU configuration "leaf sort + single gap-array merge".
 
-`value` is measured with the text already in HBM and the result left in HBM.  The same line also carries
-`host_to_host`: text in (page-locked) host memory before, L and the samples in host memory after, the
-transfers inside the timed region.
+`value` is measured with the text already in HBM and the result left in HBM, the library's timers off; the K
+steps are then repeated with an event pair around every kernel for `roofline` and `phases`.  The same line also
+carries `host_to_host`, over the same number of steps: text in (page-locked) host memory before, L and the
+samples in host memory after, the transfers inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,6 +31,10 @@ sys.path.insert(0, ROOT)
 
 METRIC = "BWT build Mbase/s end-to-end, 3.1 Gbp DNA, at 1/2/4/8 MI355X"
 DEFAULT_N = 3100000000
+VALUE_DEFINITION = ("value: (n-1) / seconds per build with the text resident in HBM before the timed region and L and the "
+                    "samples left in HBM, library timers off; host_to_host (same line, same number of steps): the text in host "
+                    "memory before and L and the samples in host memory after, every transfer inside the timed region "
+                    "(bwt_hip_pmbwt_host, what bwt::pmbwt calls)")
 
 
 class stdout_to_stderr:
@@ -178,11 +183,17 @@ def main():
     for _ in range(args.warmup):
         ctx.pmbwt(th, ns, args.seg).free()
     ctx.sync()
-    ctx.set_timing(0 if args.no_timers else 2)
-    ctx.reset_timers()
-    dt = timed_builds(ctx, th, ns, args.seg, args.steps)
-    timers = ctx.timers()
+    # The timed region runs without the library's timers (no events around the kernels); the same K steps are then
+    # repeated with an event pair around every kernel launch, on the library's own stream, for `roofline` and `phases`.
     ctx.set_timing(0)
+    dt = timed_builds(ctx, th, ns, args.seg, args.steps)
+    timers, dt_timers = {}, None
+    if not args.no_timers:
+        ctx.set_timing(2)
+        ctx.reset_timers()
+        dt_timers = timed_builds(ctx, th, ns, args.seg, args.steps)
+        timers = ctx.timers()
+        ctx.set_timing(0)
     mem = ctx.mem_stats()
 
     from bwt_amd.benchutil import phase_table, roofline
@@ -193,7 +204,8 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on the device" % args.sigma,
-        "value_definition": "text resident in HBM before the timed region, L and samples left in HBM; host_to_host has the transfers inside",
+        "value_definition": VALUE_DEFINITION,
+        "ms_per_step_with_kernel_timers": round(dt_timers * 1e3, 3) if dt_timers else None,
         "config": {"workload": workload_text(n, args.sigma, args.leaves, 1),
                    "n": n, "sigma": args.sigma, "leaves": args.leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                    "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True},
@@ -202,7 +214,7 @@ def main():
         "device_mem_peak_gb": round(mem["peak"] / 1e9, 2),
     }
     if not args.no_extras:
-        out["host_to_host"] = host_to_host(ctx, n, th, ns, args.seg, min(args.steps, 3))
+        out["host_to_host"] = host_to_host(ctx, n, th, ns, args.seg, args.steps)
         # the same text as other trees (one step each after one untimed build)
         other = {}
         for leaves in (8, 1):

@@ -95,6 +95,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_DEFER_CHAINS")) c.defer_chains = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_DC")) c.dc_mode = atoi(v);
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current
   *out = h.release();
   API_END
@@ -153,6 +154,7 @@ void bwt_hip_host_free(void *p) {
 }
 
 static void drop_text(Ctx &c) {
+  drop_dc_sample(c);
   if (c.runs) c.release(c.runs);
   c.runs = nullptr;
   c.n_runs = 0;
@@ -869,10 +871,15 @@ int bwt_hip_dist_merge_slice_grouped(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
   API_BEGIN
   need(ctx && S_dev && mL >= 0 && rn >= 0 && word_off && starts_dev && sources >= 1 && sources <= 256 && nbk >= 0, "ctx, S_dev, mL >= 0, rn >= 0, word_off, starts_dev, 1 <= sources <= 256");
   need((mL == 0 || lL_dev) && (rn == 0 || (rL_dev && words_dev)) && (mL + rn == 0 || out_dev), "device buffers");
+  need(mL + rn < (int64_t)((1ull << 32) - 2), "slice below 2^32-2 symbols");
   Ctx &c = ctx->c;
   HIP_CHECK(hipSetDevice(c.device));
   std::vector<u32> h_off((size_t)sources);
-  for (int s = 0; s < sources; s++) h_off[(size_t)s] = (u32)word_off[s];
+  for (int s = 0; s < sources; s++) {
+    need(word_off[s] >= 0 && word_off[s] < (int64_t)1 << 32 && (s == 0 || word_off[s] >= word_off[s - 1]),
+         "word_off: non-decreasing offsets below 2^32");
+    h_off[(size_t)s] = (u32)word_off[s];
+  }
   DBuf<u32> d_off(c, (size_t)sources);
   HIP_CHECK(hipMemcpyAsync(d_off.get(), h_off.data(), (size_t)sources * sizeof(u32), hipMemcpyHostToDevice, c.stream));
   gap_prefix_grouped(c, words_dev, d_off.get(), starts_dev, (u32)sources, (u32)nbk, (u64)mL, S_dev);

@@ -36,7 +36,11 @@ static size_t round_size(size_t b) {
 // arguments, memsets, copies -- goes through the address looked up here, once per device with that
 // device current (each GPU has its own copy at its own address).
 // ---------------------------------------------------------------------------
-constexpr size_t SCRATCH_BYTES = (size_t)20 << 20;
+// Sized for the largest call bwt_hip_dist_merge_slice_noalloc accepts, whatever the left block's length: 4 Mi right
+// symbols (16 MiB for the sort's second buffer) next to a left block of 2^30 to 2^31 suffixes, whose grouping has the most
+// buckets (2^18 + 1 bounds, 1 MiB) and the most tiles (512 counters for each of 512 + 513 tiles, 3 MiB), plus the tile
+// map and the scan's partial sums (a few KiB): 20.1 MiB.
+constexpr size_t SCRATCH_BYTES = (size_t)24 << 20;
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
 constexpr int MAX_DEVICES = 64;

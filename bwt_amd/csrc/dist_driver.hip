@@ -496,9 +496,16 @@ static int local_exchange(void *self, int n_ops, const bwt_hip_p2p *ops) {
   int rc = 0;
   {
     std::unique_lock<std::mutex> lock(h->mu);
+    // every transfer is checked before the first is posted; a bad list fails the whole group (the peers' matching
+    // calls would otherwise wait for ever)
+    for (int i = 0; i < n_ops; i++)
+      if (ops[i].peer < 0 || ops[i].peer >= h->world || ops[i].peer == me || ops[i].bytes < 0 || (ops[i].bytes > 0 && !ops[i].buf)) {
+        h->broken = true;
+        h->cv.notify_all();
+        return BWT_HIP_EINVAL;
+      }
     for (int i = 0; i < n_ops; i++) {
       if (!ops[i].is_send) continue;
-      if (ops[i].peer < 0 || ops[i].peer >= h->world || ops[i].peer == me) return BWT_HIP_EINVAL;
       LocalHub::Post *p = new LocalHub::Post{ops[i].buf, ops[i].bytes, dev, false};
       h->box[(size_t)me * (size_t)h->world + (size_t)ops[i].peer].push_back(p);
       mine.push_back(p);
@@ -506,10 +513,6 @@ static int local_exchange(void *self, int n_ops, const bwt_hip_p2p *ops) {
     h->cv.notify_all();
     for (int i = 0; i < n_ops && rc == 0; i++) {
       if (ops[i].is_send) continue;
-      if (ops[i].peer < 0 || ops[i].peer >= h->world || ops[i].peer == me) {
-        rc = BWT_HIP_EINVAL;
-        break;
-      }
       auto &q = h->box[(size_t)ops[i].peer * (size_t)h->world + (size_t)me];
       h->cv.wait(lock, [&] { return !q.empty() || h->broken; });
       if (h->broken) {
@@ -603,8 +606,10 @@ static RcclApi &rccl() {
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
   });
-  if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
-    fail(BWT_HIP_EINTERNAL, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
+    const char *why = dlerror();  // (a second call would return null: the message is cleared by the first)
+    fail(BWT_HIP_EINTERNAL, "librccl.so could not be loaded: %s", why ? why : "symbols missing");
+  }
   return api;
 }
 

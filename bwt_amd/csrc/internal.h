@@ -130,6 +130,18 @@ struct Ctx {
   bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
   bool repeat_probe = true;
+  // Ranks of a difference-cover sample of the whole text (DcSample below), built on first use by a leaf whose ties are
+  // dense: 0 never, 1 when a leaf asks for them, 2 for every leaf that has ties at all (tests)
+  int dc_mode = 1;
+  struct DcSample {
+    u32 v = 0, nd = 0;   // period and size of the cover
+    u32 D[8] = {};       // its residues, ascending
+    u32 n_s = 0;         // sample positions below n
+    u32 *rank = nullptr;      // rank[k] of the suffix at sample k among the sample suffixes (n_s entries, pool memory)
+    u16 *pair_tab = nullptr;  // v * v entries, see dc_pair_entry()
+    u8 *lo_tab = nullptr;     // lo_tab[r] = residues of the cover below r (v entries, behind pair_tab in one block)
+    bool valid = false;
+  } dc;
   std::vector<PhaseTimer> timers;
   struct Pending {
     int idx;
@@ -347,6 +359,10 @@ struct Block {
   i64 len() const { return b - a; }
 };
 
+// suffix_sort.hip: the ranks of the text's difference-cover sample (Ctx::dc), built on first use; the whole text must
+// have arrived.  drop_dc_sample releases them (a new text).
+void ensure_dc_sample(Ctx &c);
+void drop_dc_sample(Ctx &c);
 // suffix_sort.hip: SA of T[a:b) in full-text suffix order, absolute positions
 DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b);
 // suffix_sort.hip: bwt_leaf -- the leaf's L, special ranks and samples

@@ -15,10 +15,10 @@ namespace bwtamd {
 struct InverseParams {
   WmView wm;
   const u32 *lf_tab;
-  const u32 *samp_rank, *samp_pos;  // ordered by position; the first is the block's first position
+  const u32 *samp_rank, *samp_pos;  // ordered by position
   u32 ns;
   u64 a, b;
-  u32 e_char, e_rank;
+  u32 e_char, e_rank, s_rank;
   const u8 *T;  // compared with when `bad` is not null
   u8 *out;      // out[j - a] = decoded symbol of position j; may be null
   unsigned long long *bad;
@@ -26,29 +26,45 @@ struct InverseParams {
 
 constexpr int INV_THREADS = 256;
 
-// thread k >= 1 decodes the positions [pos_{k-1}, pos_k) from rank_k; thread 0 owns position b-1 (= e_char)
+// Thread k in [1, ns) decodes the positions [pos_{k-1}, pos_k) from rank_k and must arrive at rank_{k-1}.  Thread 0
+// decodes what lies before the first sample, [a, pos_0), and must arrive at s_rank (the rank of the suffix at a);
+// thread ns decodes what lies behind the last one, [pos_{ns-1}, b-1), starting from e_rank (the rank of the suffix at
+// b-1), and owns position b-1 itself (= e_char).  Blocks built here have samples at both ends, so both extra walks
+// are empty for them; a block brought in from outside need not.
 __global__ void __launch_bounds__(INV_THREADS) k_inverse(InverseParams P) {
   __shared__ u32 base_s[256];
   base_s[threadIdx.x] = P.lf_tab[threadIdx.x];
   __syncthreads();
   const u32 k = blockIdx.x * INV_THREADS + threadIdx.x;
-  if (k >= P.ns) return;
+  if (k > P.ns) return;
   u32 wrong = 0;
-  if (k == 0) {
+  u32 r, arrive;
+  u64 hi, lo;
+  if (k == P.ns) {
     if (P.out) P.out[P.b - 1 - P.a] = (u8)P.e_char;
     if (P.bad) wrong += P.T[P.b - 1] != P.e_char;
+    r = P.e_rank;
+    hi = P.b - 1;
+    lo = P.samp_pos[P.ns - 1];
+    arrive = P.samp_rank[P.ns - 1];
   } else {
-    u32 r = P.samp_rank[k];
-    const u64 hi = P.samp_pos[k], lo = P.samp_pos[k - 1];
-    for (u64 j = hi; j-- > lo;) {
-      const SymNext s = wm_access_lf(P.wm, base_s, r, P.e_char, P.e_rank);
-      if (P.out) P.out[j - P.a] = (u8)s.sym;
-      if (P.bad) wrong += P.T[j] != s.sym;
-      r = s.next;
-    }
-    // the walk must arrive at the previous sample's rank: catches a wrong sample even where the symbols agree
-    if (P.bad) wrong += r != P.samp_rank[k - 1];
+    r = P.samp_rank[k];
+    hi = P.samp_pos[k];
+    lo = k ? (u64)P.samp_pos[k - 1] : P.a;
+    arrive = k ? P.samp_rank[k - 1] : P.s_rank;
   }
+  if (hi < lo || hi >= P.b) {  // samples out of order or outside the block
+    if (P.bad) atomicAdd(P.bad, 1ull);
+    return;
+  }
+  for (u64 j = hi; j-- > lo;) {
+    const SymNext s = wm_access_lf(P.wm, base_s, r, P.e_char, P.e_rank);
+    if (P.out) P.out[j - P.a] = (u8)s.sym;
+    if (P.bad) wrong += P.T[j] != s.sym;
+    r = s.next;
+  }
+  // the walk must arrive at the previous sample's rank: catches a wrong sample even where the symbols agree
+  if (P.bad) wrong += r != arrive;
   if (P.bad && wrong) atomicAdd(P.bad, (unsigned long long)wrong);
 }
 
@@ -71,12 +87,13 @@ void inverse_block(Ctx &c, Block &blk, u8 *out_dev, i64 *mismatches) {
   P.b = (u64)blk.b;
   P.e_char = blk.e_char;
   P.e_rank = (u32)blk.e_rank;
+  P.s_rank = (u32)blk.s_rank;
   P.T = c.T;
   P.out = out_dev;
   P.bad = mismatches ? bad.get() : nullptr;
   {
     Phase ph(c, "inverse_chains", (double)blk.len() * blk.wm.levels);
-    hipLaunchKernelGGL(k_inverse, dim3(ceil_div((u64)blk.n_samp, INV_THREADS)), dim3(INV_THREADS), 0, c.stream, P);
+    hipLaunchKernelGGL(k_inverse, dim3(ceil_div((u64)blk.n_samp + 1, INV_THREADS)), dim3(INV_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
   }
   if (mismatches) {

@@ -211,12 +211,16 @@ struct FirstListOut {
   u32 *slot, *pos, *grp;
   u32 *total;
   size_t n;
+  // not null: receives the size of the largest group (zeroed by the caller); mask = the key bits groups are made on
+  u32 *max_group = nullptr;
+  u64 mask = 0;
   __device__ __forceinline__ void operator()(size_t i, TieHead ex, TieHead in) const {
     if (in.cnt != ex.cnt) {
       u32 k = ex.cnt;
       slot[k] = (u32)i;
       pos[k] = v.pos(i);
       grp[k] = in.hmax - 1;
+      if (max_group && (i + 1 == n || (v.key(i + 1) & mask) != (v.key(i) & mask))) atomicMax(max_group, (u32)(i + 2 - in.hmax));
     }
     if (i + 1 == n) *total = in.cnt;
   }
@@ -1425,13 +1429,518 @@ static void launch_bucket_emit(Ctx &c, const LeafEmit<V> &em, u32 n_buckets, u32
   HIP_CHECK(hipGetLastError());
 }
 
+// The refinement rounds' state: the active list (rank index, position, group name of every suffix that still shares
+// its group; in rank order), the sorted positions they index, the inverse array once doubling has begun.  Positions
+// and ranks live in the index space [a, e) of a window; n = where that space ends for good (look-ups past it read as
+// the empty suffix), b = end of the part whose ranks must come out exact.
+struct RefineRounds {
+  u64 a = 0, b = 0, e = 0, n = 0, N = 0;
+  u64 h = 0, h_exact = 0;  // depth reached; depth reached by reading the text (exact whatever the window)
+  u32 *sa_w = nullptr, *isa = nullptr;
+  u32 *wl_slot = nullptr, *wl_pos = nullptr, *wl_grp = nullptr;
+  u32 M = 0;
+  DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the list after the first round
+  int round = 0;
+};
+
+// One round through the radix passes: the list ordered by (group, secondary key), groups split where the key
+// changes.  T != null: a text round (secondary = the next K1 symbols at depth h); else a doubling round.  Returns
+// false when a doubling round had to look beyond the window.
+static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1) {
+  u32 *d_total = c.d_scalars + 8, *d_overflow = c.d_scalars + 9;
+  const u32 M = S.M;
+  const int gbits = bits_for(S.N);
+  DBuf<u64> ck0(c, M), ck1(c, M);
+  DBuf<u32> cp0(c, M), cp1(c, M);
+  // the keys carry the groups as dense indices (the names themselves come back from the slots, RefineOut)
+  DBuf<u32> dense(c, M);
+  scan_generic<u32, SumU32>(c, M, GroupHeadIn{S.wl_grp}, DenseGroupOut{dense.get(), d_total, M});
+  const u32 n_groups = read_u32(c, d_total);
+  const int dbits = bits_for(n_groups ? n_groups - 1 : 0);
+  if (dbits > gbits) fail(BWT_HIP_EINTERNAL, "refinement: %u groups in a window of %lu", n_groups, (unsigned long)S.N);
+  if (T) {
+    hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, T, S.n, S.wl_pos, (const u32 *)dense.get(), M,
+                       (u32)S.h, c.sym_bits, K1, ck0.get(), cp0.get());
+  } else {
+    hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, (const u32 *)S.isa, S.a, S.b, S.e, S.n, S.h_exact,
+                       S.wl_pos, (const u32 *)dense.get(), M, S.h, ck0.get(), cp0.get(), d_overflow);
+  }
+  HIP_CHECK(hipGetLastError());
+  dense.reset();
+  u64 *ck[2] = {ck0.get(), ck1.get()};
+  u32 *cp[2] = {cp0.get(), cp1.get()};
+  c.sort_tag = "refine:";
+  const int cc = radix_sort_u64(c, ck, cp, M, 0, 32 + dbits);
+  c.sort_tag = "";
+  DBuf<u32> ns(c, M), np(c, M), ng(c, M);
+  scan_generic<TieHead, TieHeadOp>(
+      c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull, true},
+      RefineOut{S.wl_slot, cp[cc], S.sa_w, S.isa, (u32)S.a, ns.get(), np.get(), ng.get(), d_total, M});
+  S.M = read_u32(c, d_total);
+  S.nl_slot = std::move(ns);
+  S.nl_pos = std::move(np);
+  S.nl_grp = std::move(ng);
+  S.wl_slot = S.nl_slot.get();
+  S.wl_pos = S.nl_pos.get();
+  S.wl_grp = S.nl_grp.get();
+  S.h = T ? S.h + (u64)K1 : 2 * S.h;
+  S.round++;
+  if (!T && read_u32(c, d_overflow)) return false;
+  if (S.round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
+  return true;
+}
+
+// Doubling rounds until no suffix shares its group: inside the groups in LDS (k_refine_tile) while the groups are
+// short enough, through the radix passes otherwise.  False: a look-up went beyond the window (the caller retries with
+// a longer one).
+static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
+  u32 *d_total = c.d_scalars + 8, *d_overflow = c.d_scalars + 9, *d_fail = c.d_scalars + 10;
+  bool tile_rounds = true;
+  int tile_retry = 0;
+  while (S.M > 0) {
+    const u32 M = S.M;
+    Phase ph(c, phase, (double)M * 8 * 32);
+    if (tile_rounds) {
+      // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
+      DBuf<u32> tp(c, M), tg(c, M);
+      DBuf<u8> tt(c, M);
+      const u32 n_wg = ceil_div(M, RT_TILE);
+      DBuf<u32> wg_tied(c, n_wg);
+      HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+      HIP_CHECK(hipMemsetAsync(wg_tied.get(), 0, (size_t)n_wg * sizeof(u32), c.stream));
+      RefineTileParams P{S.wl_slot, S.wl_pos, S.wl_grp, M, S.isa, S.sa_w, S.a, S.b, S.e, S.n, S.h_exact, S.h,
+                         d_overflow, d_fail, tp.get(), tg.get(), tt.get(), wg_tied.get()};
+      {
+        KernelTimer kt(c, "refine:k_refine_tile", (double)M * 25);
+        hipLaunchKernelGGL(k_refine_tile, dim3(n_wg), dim3(RT_THREADS), 0, c.stream, P);
+        HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, c.stream, (const u32 *)wg_tied.get(), n_wg, d_total);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, c.d_scalars + 8, 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      if (c.h_scalars[10] == 0) {  // d_fail
+        const bool overflow = c.h_scalars[9] != 0;
+        const u64 still = c.h_scalars[8];  // d_total
+        if (!overflow && still * 100 > (u64)M * 85) {
+          // Nearly all entries are still tied: the list stays as it is (the placed entries are groups of one from now
+          // on and cost the next round a look-up each), only the inverse array takes the new names.
+          hipLaunchKernelGGL(k_isa_update, dim3(ceil_div(ceil_div(M, 4), 256)), dim3(256), 0, c.stream, (const u8 *)tt.get(),
+                             (const u32 *)tp.get(), (const u32 *)tg.get(), M, (u32)S.a, S.isa);
+          HIP_CHECK(hipGetLastError());
+        } else if (!overflow) {
+          DBuf<u32> ns(c, M), np(c, M), ng(c, M);
+          scan_generic<u32, SumU32>(c, M, TiedIn{tt.get()},
+                                    RefineCompactOut{tt.get(), S.wl_slot, tp.get(), tg.get(), S.isa, (u32)S.a, ns.get(), np.get(), ng.get(),
+                                                     d_total, M});
+          S.M = read_u32(c, d_total);
+          S.nl_slot = std::move(ns);
+          tp = std::move(np);
+          tg = std::move(ng);
+          S.wl_slot = S.nl_slot.get();
+        }
+        S.nl_pos = std::move(tp);
+        S.nl_grp = std::move(tg);
+        S.wl_pos = S.nl_pos.get();
+        S.wl_grp = S.nl_grp.get();
+        S.h = 2 * S.h;
+        S.round++;
+        if (overflow) return false;
+        if (S.round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
+        continue;
+      }
+      tile_rounds = false;  // long groups: the later rounds only have shorter ones, but a failed try costs a pass
+      tile_retry = S.round + 3;
+    } else if (S.round >= tile_retry) {
+      tile_rounds = true;
+    }
+    if (!radix_round(c, S, nullptr, 0)) return false;
+  }
+  return true;
+}
+
+// ----------------------------------------------------------------------------
+// Ranks of a difference-cover sample of the whole text (what the reference's README.md:109 names as missing: "a
+// suffix array of sampled characters from the whole input to guarantee a single string comparison does not take too
+// long").  D is a perfect difference set modulo v: for any two positions i != j there is exactly one d < v with
+// (i + d) mod v and (j + d) mod v both in D.  Once the suffixes at the sample positions {p : p mod v in D} are
+// ranked among themselves, ANY two suffixes compare in at most v symbols plus one look-up of two ranks -- whatever
+// the text repeats.
+//
+// Ranking the sample is prefix doubling on a text |D| / v as long: sample k (its compact index: block p / v times
+// |D| plus the index of p mod v in D) shifted by a multiple of v symbols is sample k + that many |D|, so the rounds
+// above run unchanged on the index space [0, n_s) with a first shift of |D| indices = v symbols, after a radix sort
+// on the first K >= v symbols.
+// ----------------------------------------------------------------------------
+constexpr u32 DC_ND_MAX = 6;
+
+struct DcGeom {
+  u32 v, nd, n_s;
+  u64 dpack;  // residue t of the cover in byte t
+  __device__ __host__ __forceinline__ u32 pos(u32 k) const {
+    const u32 blk = k / nd;
+    return blk * v + (u32)((dpack >> (8 * (k - blk * nd))) & 0xFFu);
+  }
+};
+
+// The sample's sort keys, in decreasing order of position (TextKeys: with zero-based codes the terminator looks like
+// the smallest symbol, and of equal keys the suffixes that ran into it must come first, the shortest first; the
+// stable sort then leaves them so): key = codes of K symbols, first symbol highest; value = the sample's index.
+__global__ void k_dc_keys(const u8 *__restrict__ T, u64 n, DcGeom g, int w, int K, u32 min_sym, int one_based,
+                          u64 *__restrict__ keys, u32 *__restrict__ vals) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.n_s) return;
+  const u32 k = g.n_s - 1 - e;
+  const u64 p = g.pos(k);
+  u64 key = 0;
+  for (int j = 0; j < K; j++) {
+    const u32 ch = p + j < n ? T[p + j] : 0u;
+    const u32 code = ch ? ch - min_sym + (u32)one_based : 0u;
+    key = (key << w) | code;
+  }
+  keys[e] = key << (64 - K * w);
+  vals[e] = k;
+}
+
+struct SampleView {
+  const u64 *k;
+  const u32 *p;
+  __device__ __forceinline__ u64 key(size_t i) const { return k[i]; }
+  __device__ __forceinline__ u32 pos(size_t i) const { return p[i]; }
+  __device__ __forceinline__ void key4(size_t i0, u64 (&o)[4]) const {
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = k[i0 + j];
+  }
+  __device__ __forceinline__ void pos4(size_t i0, u32 (&o)[4]) const {
+    const uint4 x = *reinterpret_cast<const uint4 *>(p + i0);
+    o[0] = x.x;
+    o[1] = x.y;
+    o[2] = x.z;
+    o[3] = x.w;
+  }
+};
+
+// For a pair of residues (ri, rj) of two positions i, j: the smallest d with (ri + d) mod v and (rj + d) mod v both
+// in the cover, and how many sample positions lie in [i, i + d) resp. [j, j + d) -- the slots of i + d and j + d in
+// the windows of sample ranks that the two suffixes hold.  d in bits 0..4, slot of i in 5..8, slot of j in 9..12.
+static u16 dc_pair_entry(u32 v, const bool *in_cover, u32 ri, u32 rj) {
+  for (u32 d = 0; d < v; d++) {
+    if (in_cover[(ri + d) % v] && in_cover[(rj + d) % v]) {
+      u32 si = 0, sj = 0;
+      for (u32 t = 0; t < d; t++) {
+        si += in_cover[(ri + t) % v];
+        sj += in_cover[(rj + t) % v];
+      }
+      return (u16)(d | (si << 5) | (sj << 9));
+    }
+  }
+  fail(BWT_HIP_EINTERNAL, "difference cover modulo %u does not cover (%u, %u)", v, ri, rj);
+}
+
+void drop_dc_sample(Ctx &c) {
+  if (c.dc.rank) c.release(c.dc.rank);
+  if (c.dc.pair_tab) c.release(c.dc.pair_tab);
+  c.dc = Ctx::DcSample();
+}
+
+void ensure_dc_sample(Ctx &c) {
+  if (c.dc.valid) return;
+  if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
+  c.wait_text((u64)c.n);
+  Phase ph(c, "dc_sample", (double)c.n);
+  drop_dc_sample(c);
+  // symbol codes as the leaf sort's keys have them (TextKeys): zero-based when the alphabet has 2^k symbols
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
+  const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;
+  const int one_based = pow2 ? 0 : 1;
+  const int w = bits_for((u64)(span + one_based));
+  const int K = 64 / w;  // symbols of a sort key: the cover's period must not exceed it
+  // perfect difference sets: every non-zero residue is the difference of exactly one pair
+  static const struct { u32 v, nd, D[DC_ND_MAX]; } covers[] = {
+      {31, 6, {0, 1, 3, 8, 12, 18}}, {21, 5, {0, 1, 4, 14, 16}}, {13, 4, {0, 1, 3, 9}}, {7, 3, {0, 1, 3}}};
+  int pick = 3;
+  for (int t = 3; t >= 0; t--)
+    if ((int)covers[t].v <= K) pick = t;
+  Ctx::DcSample &dc = c.dc;
+  dc.v = covers[pick].v;
+  dc.nd = covers[pick].nd;
+  DcGeom g;
+  g.v = dc.v;
+  g.nd = dc.nd;
+  g.dpack = 0;
+  bool in_cover[32] = {};
+  for (u32 t = 0; t < dc.nd; t++) {
+    dc.D[t] = covers[pick].D[t];
+    g.dpack |= (u64)dc.D[t] << (8 * t);
+    in_cover[dc.D[t]] = true;
+  }
+  const u64 n = (u64)c.n;
+  const u64 last_blk = (n - 1) / dc.v;
+  u64 n_s = last_blk * dc.nd;
+  for (u32 t = 0; t < dc.nd; t++) n_s += (last_blk * dc.v + dc.D[t] < n);
+  dc.n_s = (u32)n_s;
+  g.n_s = dc.n_s;
+  // the tables of the pairwise comparison
+  {
+    std::vector<u16> tab((size_t)dc.v * dc.v + (dc.v + 1) / 2 + 1);
+    for (u32 ri = 0; ri < dc.v; ri++)
+      for (u32 rj = 0; rj < dc.v; rj++) tab[(size_t)ri * dc.v + rj] = dc_pair_entry(dc.v, in_cover, ri, rj);
+    u8 *lo = reinterpret_cast<u8 *>(tab.data() + (size_t)dc.v * dc.v);
+    for (u32 r = 0; r < dc.v; r++) {
+      u32 below = 0;
+      for (u32 t = 0; t < dc.nd; t++) below += dc.D[t] < r;
+      lo[r] = (u8)below;
+    }
+    dc.pair_tab = (u16 *)c.alloc(tab.size() * sizeof(u16));
+    dc.lo_tab = reinterpret_cast<u8 *>(dc.pair_tab + (size_t)dc.v * dc.v);
+    HIP_CHECK(hipMemcpyAsync(dc.pair_tab, tab.data(), tab.size() * sizeof(u16), hipMemcpyHostToDevice, c.stream));
+    c.sync();  // `tab` is on the stack
+  }
+  const size_t N = dc.n_s;
+  u32 *d_total = c.d_scalars + 8;
+  DBuf<u32> isa(c, N + 8);
+  if (N == 1) {
+    HIP_CHECK(hipMemsetAsync(isa.get(), 0, sizeof(u32), c.stream));
+  } else {
+    DBuf<u64> kb0(c, N), kb1(c, N);
+    DBuf<u32> vb0(c, N), vb1(c, N);
+    {
+      KernelTimer kt(c, "dc:k_dc_keys", (double)N * (K + 12));
+      hipLaunchKernelGGL(k_dc_keys, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, c.T, n, g, w, K, min_sym, one_based, kb0.get(),
+                         vb0.get());
+      HIP_CHECK(hipGetLastError());
+    }
+    u64 *keys[2] = {kb0.get(), kb1.get()};
+    u32 *vals[2] = {vb0.get(), vb1.get()};
+    const int low_bit = 64 - K * w;
+    c.sort_tag = "dc:";
+    const int cur = radix_sort_u64(c, keys, vals, N, low_bit & ~7, 64);
+    c.sort_tag = "";
+    const u64 sym_mask = ~0ull << low_bit;
+    SampleView sv{keys[cur], vals[cur]};
+    DBuf<u32> wl_slot(c, N), wl_pos(c, N), wl_grp(c, N);
+    scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<SampleView>{sv, N, sym_mask},
+                                     FirstListOut<SampleView>{sv, wl_slot.get(), wl_pos.get(), wl_grp.get(), d_total, N});
+    RefineRounds R;
+    R.a = 0;
+    R.b = R.e = R.n = R.N = N;
+    R.h = dc.nd;  // a shift of |D| indices is a shift of v <= K symbols: the depth the keys have reached
+    R.h_exact = R.h;
+    R.sa_w = vals[cur];
+    R.isa = isa.get();
+    R.wl_slot = wl_slot.get();
+    R.wl_pos = wl_pos.get();
+    R.wl_grp = wl_grp.get();
+    R.M = read_u32(c, d_total);
+    hipLaunchKernelGGL(k_isa_init_untied<SampleView>, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, ViewTies<SampleView>{sv, N, sym_mask},
+                       (const u32 *)vals[cur], 0u, (u32)N, isa.get());
+    if (R.M > 0) hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(R.M, 256)), dim3(256), 0, c.stream, R.wl_pos, R.wl_grp, R.M, 0u, isa.get());
+    HIP_CHECK(hipGetLastError());
+    if (!doubling_rounds(c, R, "dc_doubling_round")) fail(BWT_HIP_EINTERNAL, "difference-cover sample: a look-up beyond the text");
+    c.sync();  // the sort's buffers die here
+  }
+  dc.rank = isa.get();
+  isa.p = nullptr;  // kept by the context until the text goes
+  dc.valid = true;
+}
+
+struct DcView {
+  const u32 *rank;
+  const u16 *pair_tab;
+  const u8 *lo_tab;
+  u32 v, nd, n_s;
+};
+
+// One pass from the window sorted on its first K0 symbols to the leaf's BWT, ties settled by the sample ranks.  The
+// window is the leaf itself (no slack: the ranks are those of the whole text).  A workgroup takes the groups of equal
+// keys that START in its DT_TILE window ranks (a group's members are consecutive), at most DT_CAP entries.  A suffix
+// alone in its group is final where it stands.  A member of a longer group loads what any comparison with another
+// member can need -- the ranks of the |D| sample positions in [p, p + v) and the symbols K0 .. v-2 behind p, packed --
+// and counts the members below it: for residues (p mod v, q mod v) a table gives the one shift d < v that makes
+// both p + d and q + d sample positions; the suffixes agree on their first K0 symbols, compare on the symbols K0 .. d-1
+// from the packed words, and then on the two ranks.  A group that does not fit raises *fail (the caller has checked
+// the largest group beforehand).
+constexpr int DT_THREADS = 256;
+constexpr int DT_TILE = 512;
+constexpr int DT_CAP = 1024;
+
+// X128: the packed symbols take more than 64 bits (short keys: small windows)
+template <class View, bool X128>
+__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0, u32 nx, u32 sbits, u32 min_sym) {
+  __shared__ u32 Rw[DT_CAP * DC_ND_MAX];  // first the entries' keys (two words each), then the windows of sample ranks
+  // the symbols K0 .. K0+nx-1 behind the position as codes of sbits bits (symbol - min_sym + 1; 0 = the terminator and
+  // beyond), first symbol in the highest bits of Xs, continued in Xl
+  __shared__ u64 Xs[DT_CAP];
+  __shared__ u64 Xl[X128 ? DT_CAP : 1];
+  __shared__ u32 Bp[DT_CAP];              // positions
+  __shared__ u16 gs_s[DT_CAP], ge_s[DT_CAP];
+  __shared__ u16 meta[DT_CAP];            // position mod v; bit 8: the suffix ends inside its key
+  __shared__ u8 sym_s[DT_CAP];            // preceding symbol
+  __shared__ u16 tab_s[32 * 32];
+  __shared__ u32 tmx[DT_THREADS];
+  __shared__ u32 scan_s[17];
+  __shared__ u32 bounds[2];
+  static_assert(DT_CAP == 4 * DT_THREADS && DC_ND_MAX * 4 >= 8, "four entries per thread; the keys fit the rank windows");
+  const u32 tid = threadIdx.x;
+  const u64 base = (u64)blockIdx.x * DT_TILE;
+  const u32 cnt = E.N - base < (u64)DT_CAP ? (u32)(E.N - base) : (u32)DT_CAP;
+  u64 *keyb = reinterpret_cast<u64 *>(Rw);
+  const u64 prev_key = base ? (E.v.key(base - 1) & E.sym_mask) : 0ull;
+  if (tid < 2) bounds[tid] = DT_CAP;
+  for (u32 i = tid; i < dc.v * dc.v; i += DT_THREADS) tab_s[i] = dc.pair_tab[i];
+  for (u32 i = tid; i < cnt; i += DT_THREADS) {
+    const u64 k = E.v.key(base + i);
+    keyb[i] = k & E.sym_mask;
+    sym_s[i] = (u8)k;
+    Bp[i] = E.v.pos(base + i);
+  }
+  __syncthreads();
+  auto is_head = [&](u32 i) { return (base + i == 0) || keyb[i] != (i ? keyb[i - 1] : prev_key); };
+  for (u32 i = tid; i < cnt; i += DT_THREADS)
+    if (is_head(i)) atomicMin(&bounds[i < (u32)DT_TILE ? 0 : 1], i);
+  __syncthreads();
+  const u32 lo = bounds[0];
+  if (lo == (u32)DT_CAP) return;  // no group starts here: the stretch belongs to a group of an earlier workgroup
+  u32 hi = bounds[1];
+  if (hi == (u32)DT_CAP) {
+    if (base + cnt == E.N) {
+      hi = cnt;
+    } else {
+      if (tid == 0) *E.fail = 1;  // the last group runs past what this workgroup holds
+      return;
+    }
+  }
+  // first index of every entry's group: running maximum of the head indices; thread t owns entries 4t .. 4t+3
+  u32 hv[4], mx = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    hv[j] = (i >= lo && i < hi && is_head(i)) ? i + 1 : 0u;
+    mx = mx > hv[j] ? mx : hv[j];
+  }
+  u32 tot;
+  tmx[tid] = block_scan_incl<OpMax>(mx, scan_s, &tot);
+  __syncthreads();
+  u32 run = tid ? tmx[tid - 1] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = tid * 4 + j;
+    run = run > hv[j] ? run : hv[j];
+    if (i >= lo && i < hi) gs_s[i] = (u16)(run - 1);
+  }
+  __syncthreads();
+  for (u32 i = lo + tid; i < hi; i += DT_THREADS) {
+    if (i > lo && gs_s[i] == i) ge_s[gs_s[i - 1]] = (u16)i;
+    if (i + 1 == hi) ge_s[gs_s[i]] = (u16)hi;
+  }
+  __syncthreads();  // the keys are dead: their room takes the rank windows
+  // suffixes alone in their group are final; the others load what the comparisons need
+  const u8 *__restrict__ T = E.T;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 i = lo + tid + r * DT_THREADS;
+    if (i >= hi) continue;
+    const u32 s = gs_s[i], t = ge_s[s];
+    const u32 p = Bp[i];
+    if (t - s == 1) {
+      E.place(base + i, p, sym_s[i]);
+      continue;
+    }
+    const u32 blk = p / dc.v, res = p - blk * dc.v;
+    meta[i] = (u16)(res | ((u64)p + K0 >= E.n ? 0x100u : 0u));
+    const u32 k0 = blk * dc.nd + dc.lo_tab[res];
+    for (u32 x = 0; x < dc.nd; x++) Rw[i * DC_ND_MAX + x] = k0 + x < dc.n_s ? dc.rank[k0 + x] : 0u;
+    u64 xh = 0, xl = 0;
+    const u64 q = (u64)p + K0;
+    for (u32 x = 0; x < nx; x++) {
+      const u32 ch = q + x < E.n ? T[q + x] : 0u;
+      const u64 code = ch ? (u64)(ch - min_sym + 1u) : 0ull;
+      const u32 at = (x + 1) * sbits;  // the code's lowest bit lies `at` bits below the top of the 128
+      if (at <= 64) xh |= code << (64 - at);
+      else if (X128) {
+        xl |= code << (128 - at);
+        if (at - sbits < 64) xh |= code >> (at - 64);  // a code across the two words
+      }
+    }
+    Xs[i] = xh;
+    if (X128) Xl[i] = xl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 i = lo + tid + r * DT_THREADS;
+    if (i >= hi) continue;
+    const u32 s = gs_s[i], t = ge_s[s];
+    if (t - s == 1) continue;
+    const u32 mi = meta[i], ri = mi & 0xFFu, pi = Bp[i];
+    const bool short_i = (mi & 0x100u) != 0;
+    const u64 xi = Xs[i], xli = X128 ? Xl[i] : 0ull;
+    const u16 *row = tab_s + ri * dc.v;
+    const u32 *mine = Rw + i * DC_ND_MAX;
+    u32 below = 0;
+    for (u32 j = s; j < t; j++) {
+      if (j == i) continue;
+      const u32 mj = meta[j];
+      bool less;  // is the suffix of entry j below that of entry i?
+      if ((mj | mi) & 0x100u) {
+        // a suffix that ends inside its key is below every longer one with the same key; of two such the shorter
+        const bool short_j = (mj & 0x100u) != 0;
+        less = short_j && (!short_i || Bp[j] > pi);
+      } else {
+        const u32 e = row[mj & 0xFFu];
+        const u32 d = e & 31u;
+        bool decided = false;
+        less = false;
+        if (d > K0) {
+          const u32 nb = (d - K0) * sbits;  // the leading bits that hold the symbols K0 .. d-1
+          const u64 xj = Xs[j];
+          if (!X128 || nb <= 64) {
+            const u64 a = xi >> (64 - nb), b = xj >> (64 - nb);
+            if (a != b) {
+              less = b < a;
+              decided = true;
+            }
+          } else if (xi != xj) {
+            less = xj < xi;
+            decided = true;
+          } else {
+            const u64 a = xli >> (128 - nb), b = Xl[j] >> (128 - nb);
+            if (a != b) {
+              less = b < a;
+              decided = true;
+            }
+          }
+        }
+        if (!decided) less = Rw[j * DC_ND_MAX + ((e >> 9) & 15u)] < mine[(e >> 5) & 15u];
+      }
+      below += less;
+    }
+    E.place(base + s + below, pi, sym_s[i]);
+  }
+}
+
+// Is the pass above the way to finish this window?  M tied suffixes of N, the largest group, K0 symbols in the keys.
+static bool dc_pass_applies(Ctx &c, u64 N, u32 M, u32 max_group, int K0, bool repeats) {
+  if (c.dc_mode <= 0 || M == 0) return false;
+  if (max_group > (u32)(DT_CAP - DT_TILE + 1)) return false;  // a group that may not fit a workgroup
+  if (c.dc_mode >= 2) return true;
+  // dense ties (every round of the general path would go over most of the window) or a text known to repeat itself
+  return c.dc.valid || repeats || (u64)M * 8 >= N;
+}
+
 // Everything after the round-0 sort: tie list, refinement, emit.  sa_w: the writable positions (pairs
 // layout) or null; e_w: the writable elements (packed layout) or null.  scratch: 2N free 32-bit words for
 // the first active list; grp_buf: N more words (pairs: the unused value buffer).
+// dc_state: 1 = the window is the leaf itself on purpose, ties are to be settled by the difference-cover sample ranks;
+// 0 = undecided; -1 = not by them.  *redo (on a false return): REDO_DC = sort the leaf alone and come back with
+// dc_state 1; REDO_NO_DC = the sample ranks cannot finish this window, come back with dc_state -1; 0 = the window was
+// too short (the caller retries with a longer one).
+constexpr int REDO_DC = 1, REDO_NO_DC = 2;
 template <class View>
 static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_mask, View v, u32 *sa_w, u64 *e_w,
-                          u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out, BucketState *bs = nullptr,
-                          const TextKeys *tk = nullptr, bool skip_direct = false) {
+                          u32 *scratch, u32 *grp_buf, const EmitParams *E, DBuf<u32> *sa_out, int dc_state, int *redo,
+                          BucketState *bs = nullptr, const TextKeys *tk = nullptr, bool skip_direct = false) {
   const int K1 = 32 / c.sym_bits;  // the text rounds read the symbols as they are
   u32 *d_total = c.d_scalars + 8;
   u32 *d_overflow = c.d_scalars + 9;
@@ -1501,21 +2010,81 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   u32 *wl_slot = scratch;
   u32 *wl_pos = scratch + N;
   u32 *wl_grp = grp_buf;
-  u32 M;
+  u32 M, max_group;
   {
     Phase ph(c, "leaf_group", (double)N * (e_w ? 16 : 16));
+    u32 *d_maxg = c.d_scalars + 11;
+    HIP_CHECK(hipMemsetAsync(d_maxg, 0, sizeof(u32), c.stream));
     scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<View>{v, N, sym_mask},
-                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N});
-    M = read_u32(c, d_total);
+                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N, d_maxg, sym_mask});
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, d_total, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 11, d_maxg, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    M = c.h_scalars[8];
+    max_group = c.h_scalars[11];
   }
-  u64 h = (u64)K0;
-  int round = 0;
+  // Dense or deep ties: one pass that settles every group with the ranks of the text's difference-cover sample,
+  // instead of log2(longest repeat) doubling rounds over all of them.
+  if (dc_state >= 0 && M > 0) {
+    const bool wanted = dc_state == 1 ? c.dc_mode > 0 && max_group <= (u32)(DT_CAP - DT_TILE + 1)
+                                      : dc_pass_applies(c, N, M, max_group, K0, skip_direct);
+    if (dc_state == 1 && !wanted) {
+      *redo = REDO_NO_DC;
+      return false;
+    }
+    if (wanted && e != b) {
+      *redo = REDO_DC;
+      return false;
+    }
+    if (wanted) {
+      ensure_dc_sample(c);
+      const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+      const u32 xbits = (u32)bits_for((u64)(c.max_sym - (int)min_sym + 1));  // codes symbol - min_sym + 1
+      const u32 nx = c.dc.v - 1 > (u32)K0 ? c.dc.v - 1 - (u32)K0 : 0u;
+      if (nx * xbits > 128) {
+        *redo = REDO_NO_DC;
+        return false;
+      }
+      Phase ph(c, "leaf_dc_emit", (double)N * (e_w ? 8 : 12) + (double)M * (c.dc.nd * 4 + nx) + (double)(b - a) * 2);
+      LeafEmit<View> em;
+      memset(&em, 0, sizeof(em));
+      if (E) static_cast<EmitParams &>(em) = *E;
+      em.sa_out = sa_out ? res.get() : nullptr;
+      em.v = v;
+      em.N = N;
+      em.sym_mask = sym_mask;
+      em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
+      em.h = (u64)K0;
+      em.leaf_end = (u32)b;
+      em.fail = d_fail;
+      em.T = c.T;
+      em.n = (u64)c.n;
+      HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+      const DcView dv{c.dc.rank, c.dc.pair_tab, c.dc.lo_tab, c.dc.v, c.dc.nd, c.dc.n_s};
+      const dim3 grid(ceil_div(N, DT_TILE)), block(DT_THREADS);
+      if (nx * xbits > 64) hipLaunchKernelGGL((k_dc_emit<View, true>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym);
+      else hipLaunchKernelGGL((k_dc_emit<View, false>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym);
+      HIP_CHECK(hipGetLastError());
+      if (read_u32(c, d_fail) != 0) {
+        *redo = REDO_NO_DC;
+        return false;
+      }
+      if (sa_out) *sa_out = std::move(res);
+      return true;
+    }
+  }
+  RefineRounds R;
+  R.a = (u64)a;
+  R.b = (u64)b;
+  R.e = (u64)e;
+  R.n = (u64)c.n;
+  R.N = N;
+  R.h = (u64)K0;
+  R.wl_slot = wl_slot;
+  R.wl_pos = wl_pos;
+  R.wl_grp = wl_grp;
+  R.M = M;
   DBuf<u32> isa, sa_mat;
-  u64 h_exact = 0;  // depth of the ranks when the inverse array is built: reached by reading the text
-  DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the current list after the first round
-  const int gbits = bits_for(N);
-  bool tile_rounds = true;  // doubling rounds inside the groups (k_refine_tile) while the groups are short enough
-  int tile_retry = 0;
   if (M > 0 && !sa_w) {
     // the refinement rounds rewrite positions: give the packed layout a position array of its own
     // (tied suffixes then take their BWT symbol from the text, as in the pairs layout)
@@ -1526,114 +2095,27 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     sa_w = sa_mat.get();
     set_positions(v, sa_w);
   }
-  while (M > 0) {
-    // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
-    // doubling rounds double it but need the inverse array of the whole window (one random write per
-    // window position).  Sparse ties get a few text rounds first; dense or deep ties go to doubling.
-    const bool text_round = !isa.get() && round < 8 && (u64)M * 16 < N;
-    Phase ph(c, text_round ? "leaf_text_round" : "leaf_doubling_round", (double)M * 8 * 32);
-    if (!text_round && !isa.get()) {
-      h_exact = h;
-      isa = DBuf<u32>(c, N);
-      if (round == 0)  // the list is still the one the keys gave: tied = shares its key with a neighbour
-        hipLaunchKernelGGL(k_isa_init_untied<View>, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, ViewTies<View>{v, N, sym_mask},
-                           (const u32 *)sa_w, (u32)a, (u32)N, isa.get());
-      else
-        hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N, isa.get());
-      hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, wl_pos, wl_grp, M, (u32)a, isa.get());
-      HIP_CHECK(hipGetLastError());
-    }
-    if (!text_round && tile_rounds) {
-      // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
-      DBuf<u32> tp(c, M), tg(c, M);
-      DBuf<u8> tt(c, M);
-      const u32 n_wg = ceil_div(M, RT_TILE);
-      DBuf<u32> wg_tied(c, n_wg);
-      HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
-      HIP_CHECK(hipMemsetAsync(wg_tied.get(), 0, (size_t)n_wg * sizeof(u32), c.stream));
-      RefineTileParams P{wl_slot, wl_pos, wl_grp, M, isa.get(), sa_w, (u64)a, (u64)b, (u64)e, (u64)c.n, h_exact, h,
-                         d_overflow, d_fail, tp.get(), tg.get(), tt.get(), wg_tied.get()};
-      {
-        KernelTimer kt(c, "refine:k_refine_tile", (double)M * 25);
-        hipLaunchKernelGGL(k_refine_tile, dim3(n_wg), dim3(RT_THREADS), 0, c.stream, P);
-        HIP_CHECK(hipGetLastError());
-      }
-      hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, c.stream, (const u32 *)wg_tied.get(), n_wg, d_total);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, c.d_scalars + 8, 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-      c.sync();
-      if (c.h_scalars[10] == 0) {  // d_fail
-        const bool overflow = c.h_scalars[9] != 0;
-        const u64 still = c.h_scalars[8];  // d_total
-        if (!overflow && still * 100 > (u64)M * 85) {
-          // Nearly all entries are still tied: the list stays as it is (the placed entries are groups of one from now
-          // on and cost the next round a look-up each), only the inverse array takes the new names.
-          hipLaunchKernelGGL(k_isa_update, dim3(ceil_div(ceil_div(M, 4), 256)), dim3(256), 0, c.stream, (const u8 *)tt.get(),
-                             (const u32 *)tp.get(), (const u32 *)tg.get(), M, (u32)a, isa.get());
-          HIP_CHECK(hipGetLastError());
-        } else if (!overflow) {
-          DBuf<u32> ns(c, M), np(c, M), ng(c, M);
-          scan_generic<u32, SumU32>(c, M, TiedIn{tt.get()},
-                                    RefineCompactOut{tt.get(), wl_slot, tp.get(), tg.get(), isa.get(), (u32)a, ns.get(), np.get(), ng.get(),
-                                                     d_total, M});
-          M = read_u32(c, d_total);
-          nl_slot = std::move(ns);
-          tp = std::move(np);
-          tg = std::move(ng);
-          wl_slot = nl_slot.get();
-        }
-        nl_pos = std::move(tp);
-        nl_grp = std::move(tg);
-        wl_pos = nl_pos.get();
-        wl_grp = nl_grp.get();
-        h = 2 * h;
-        round++;
-        if (overflow) return false;
-        if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
-        continue;
-      }
-      tile_rounds = false;  // long groups: the later rounds only have shorter ones, but a failed try costs a pass
-      tile_retry = round + 3;
-    } else if (!text_round && round >= tile_retry) {
-      tile_rounds = true;
-    }
-    DBuf<u64> ck0(c, M), ck1(c, M);
-    DBuf<u32> cp0(c, M), cp1(c, M);
-    // the keys carry the groups as dense indices (the names themselves come back from the slots, RefineOut)
-    DBuf<u32> dense(c, M);
-    scan_generic<u32, SumU32>(c, M, GroupHeadIn{wl_grp}, DenseGroupOut{dense.get(), d_total, M});
-    const u32 n_groups = read_u32(c, d_total);
-    const int dbits = bits_for(n_groups ? n_groups - 1 : 0);
-    if (dbits > gbits) fail(BWT_HIP_EINTERNAL, "refinement: %u groups in a window of %lu", n_groups, (unsigned long)N);
-    if (text_round) {
-      hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, c.T, (u64)c.n, wl_pos,
-                         (const u32 *)dense.get(), M, (u32)h, c.sym_bits, K1, ck0.get(), cp0.get());
-    } else {
-      hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, isa.get(), (u64)a, (u64)b,
-                         (u64)e, (u64)c.n, h_exact, wl_pos, (const u32 *)dense.get(), M, h, ck0.get(), cp0.get(), d_overflow);
-    }
+  R.sa_w = sa_w;
+  // Text rounds cost O(M) and need no inverse array, but deepen the comparison by only K1 symbols;
+  // doubling rounds double it but need the inverse array of the whole window (one random write per
+  // window position).  Sparse ties get a few text rounds first; dense or deep ties go to doubling.
+  while (R.M > 0 && R.round < 8 && (u64)R.M * 16 < N) {
+    Phase ph(c, "leaf_text_round", (double)R.M * 8 * 32);
+    radix_round(c, R, c.T, K1);
+  }
+  if (R.M > 0) {
+    // ranks at this depth came from reading the text itself: exact whatever the window is
+    R.h_exact = R.h;
+    isa = DBuf<u32>(c, N);
+    R.isa = isa.get();
+    if (R.round == 0)  // the list is still the one the keys gave: tied = shares its key with a neighbour
+      hipLaunchKernelGGL(k_isa_init_untied<View>, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, ViewTies<View>{v, N, sym_mask},
+                         (const u32 *)sa_w, (u32)a, (u32)N, isa.get());
+    else
+      hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N, isa.get());
+    hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(R.M, 256)), dim3(256), 0, c.stream, R.wl_pos, R.wl_grp, R.M, (u32)a, isa.get());
     HIP_CHECK(hipGetLastError());
-    dense.reset();
-    u64 *ck[2] = {ck0.get(), ck1.get()};
-    u32 *cp[2] = {cp0.get(), cp1.get()};
-    c.sort_tag = "refine:";
-    int cc = radix_sort_u64(c, ck, cp, M, 0, 32 + dbits);
-    c.sort_tag = "";
-    DBuf<u32> ns(c, M), np(c, M), ng(c, M);
-    scan_generic<TieHead, TieHeadOp>(
-        c, M, GroupIn<PlainKeys>{PlainKeys{ck[cc]}, M, ~0ull, true},
-        RefineOut{wl_slot, cp[cc], sa_w, isa.get(), (u32)a, ns.get(), np.get(), ng.get(), d_total, M});
-    M = read_u32(c, d_total);
-    nl_slot = std::move(ns);
-    nl_pos = std::move(np);
-    nl_grp = std::move(ng);
-    wl_slot = nl_slot.get();
-    wl_pos = nl_pos.get();
-    wl_grp = nl_grp.get();
-    h = text_round ? h + (u64)K1 : 2 * h;
-    round++;
-    if (!text_round && read_u32(c, d_overflow)) return false;
-    if (round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
+    if (!doubling_rounds(c, R, "leaf_doubling_round")) return false;
   }
   LeafEmit<View> em;
   memset(&em, 0, sizeof(em));
@@ -1810,7 +2292,7 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
-static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out) {
+static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out, int dc_state, int *redo) {
   const u64 N = (u64)(e - a);
   const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
   const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
@@ -1850,7 +2332,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
     }
     PackedView v{el[cur], nullptr, (u32)a, (u32)((1ull << kp.pbits) - 1), kp.pbits};
     return finish_window<PackedView>(c, a, b, e, N, K0, sym_mask, v, nullptr, el[cur], (u32 *)el[cur ^ 1], grp.get(), E,
-                                     sa_out, &bs, &tk, repeats);
+                                     sa_out, dc_state, redo, &bs, &tk, repeats);
   }
   const u32 stride = (u32)((N + 3) & ~(u64)3);  // 32-bit words between a key's low and high word
   DBuf<u64> kb0(c, stride), kb1(c, stride);
@@ -1864,7 +2346,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   }
   PairsView v{reinterpret_cast<const u32 *>(keys[cur]), reinterpret_cast<const u32 *>(keys[cur]) + stride, vals[cur]};
   return finish_window<PairsView>(c, a, b, e, N, K0, sym_mask, v, vals[cur], nullptr, (u32 *)keys[cur ^ 1],
-                                  vals[cur ^ 1], E, sa_out, nullptr, nullptr, repeats);
+                                  vals[cur ^ 1], E, sa_out, dc_state, redo, nullptr, nullptr, repeats);
 }
 
 static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *sa_out) {
@@ -1892,11 +2374,28 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
     }
     if (slack > c.n - b) slack = c.n - b;
   }
+  // A text whose sample ranks exist (an earlier leaf found it repetitive) is sorted leaf by leaf without slack: ties
+  // are settled by those ranks, which are the whole text's.
+  int dc_state = (c.dc_mode > 0 && c.dc.valid) ? 1 : 0;
   for (;;) {
+    const i64 e = dc_state == 1 ? b : b + slack;
     // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it
-    c.wait_text((u64)(b + slack) + DF_DEPTH + 128);
-    if (sort_window(c, a, b, b + slack, E, sa_out)) return;
-    if (b + slack >= c.n) fail(BWT_HIP_EINTERNAL, "suffix sort overflowed a window that ends at n");
+    c.wait_text((u64)e + DF_DEPTH + 128);
+    int redo = 0;
+    if (sort_window(c, a, b, e, E, sa_out, dc_state, &redo)) return;
+    if (redo == REDO_DC) {
+      dc_state = 1;
+      continue;
+    }
+    if (redo == REDO_NO_DC) {
+      dc_state = -1;
+      continue;
+    }
+    if (e >= c.n) fail(BWT_HIP_EINTERNAL, "suffix sort overflowed a window that ends at n");
+    if (dc_state == 1) {  // (ties so sparse that the rounds ran instead, and looked past the leaf's end)
+      dc_state = -1;
+      continue;
+    }
     slack = slack * 8;
     if (slack > c.n - b) slack = c.n - b;
   }

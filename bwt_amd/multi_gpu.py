@@ -289,24 +289,34 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
         if blk is not None:
             blk.free()
     ctx.sync()
-    ctx.set_timing(0 if getattr(args, "no_timers", False) else 2)
-    ctx.reset_timers()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        if last is not None:
-            last.free()
-        last = step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item()) / args.steps
-    timers = ctx.timers()
+
+    def timed_steps(last):
+        """K steps between barriers; the slowest rank's seconds per step, and what the last step left behind."""
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if last is not None:
+                last.free()
+            last = step()
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()) / args.steps, last
+
+    # the timed region runs with the library's timers off; the same K steps again with an event pair around every
+    # kernel give `roofline` and the phase table
     ctx.set_timing(0)
+    dt, last = timed_steps(None)
+    timers, dt_timers = {}, None
+    if not getattr(args, "no_timers", False):
+        ctx.set_timing(2)
+        ctx.reset_timers()
+        dt_timers, last = timed_steps(last)
+        timers = ctx.timers()
+        ctx.set_timing(0)
     verified = None
     if algo in ("native", "dist") and not os.environ.get("BWT_MGPU_NO_VERIFY"):
         verified = verify_against_one_gpu(ctx, last.d if algo == "dist" else last, algo, rank, world,
@@ -319,6 +329,8 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
+            "value_definition": "(n-1) / seconds per build (slowest rank, between barriers), the text resident in every GPU's HBM before the timed region, L left sliced over the GPUs, library timers off",
+            "ms_per_step_with_kernel_timers": round(dt_timers * 1e3, 3) if dt_timers else None,
             "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
                                     "subtree (RCCL send/recv); L stays sliced over the GPUs, every GPU keeps the samples of its own text range"
                                     if algo in ("dist", "native") else

@@ -18,8 +18,10 @@
        the host after every public call, as the reference leaves them;
      - the workspace W of bwt_merge/bwt_rec is accepted and not used (merges
        write to a fresh device buffer); pmbwt does not allocate it;
-     - build_gap / gap_array / resample_sa have no host form here: they exist
-       only inside bwt_hip_merge;
+     - build_gap and resample_sa exist for host code written against them
+       (build_gap: the chains and the histogram on the device through
+       bwt_hip_gap, the counters then filled into the caller's gap_array);
+       bwt_merge itself does not go through them: a merge stays on the device;
      - failures print to stderr and abort(), as check() does in the reference.
    Like the reference, include this from one translation unit per program. */
 #pragma once
@@ -211,6 +213,42 @@ namespace bwt {
       stat.end(ts_event_bwt_sample_sa);
       return 1;
     }
+
+    /* The samples of the merged block [a,b) from those of its halves l = [a,c) and r = [c,b)
+       (reference include/bwt.h:366-453): the two sets in position order form one sequence of nn samples, of which
+       sample i is kept while (kept so far) * (nn-1) <= i * (ns-1); a left sample's new rank is its rank plus the
+       right suffixes in front of it, gap[a] + ... + gap[rank]; a right sample's rank has had its g added by
+       build_gap and lies c too high.  Sets s_rank and e_rank of this block. */
+    int resample_sa(sampled_suffix_array & l, sampled_suffix_array & r, idx_t c, idx_t ns, gap_array & gap,
+                    mallocator & mem, bwt_opt & opt) {
+      stat.start(ts_event_bwt_resample_sa);
+      ssa.init(ns, mem, opt.ssa_init_gran);
+      const idx_t nn = l.n + r.n;
+      idx_t seen = 0, kept = 0;
+      for (ssa_iterator it = l.pos_begin(mem); it.has_next(); it.next(), seen++) {
+        const idx_t rank = it.e->rank, pos = it.e->pos;
+        assert(a <= rank && rank < c);
+        if (kept * (nn - 1) <= seen * (ns - 1)) {
+          const idx_t nr = rank + gap.sum(rank);
+          assert(a <= nr && nr < b);
+          ssa.put(nr, pos);
+          if (pos == a) s_rank = nr;
+          kept++;
+        }
+      }
+      for (ssa_iterator it = r.pos_begin(mem); it.has_next(); it.next(), seen++) {
+        const idx_t nr = it.e->rank - c, pos = it.e->pos;
+        assert(a <= nr && nr < b);
+        if (kept * (nn - 1) <= seen * (ns - 1)) {
+          ssa.put(nr, pos);
+          if (pos == b - 1) e_rank = nr;
+          kept++;
+        }
+      }
+      check(s_rank != -1 && e_rank != -1);
+      stat.end(ts_event_bwt_resample_sa);
+      return 1;
+    }
   };
 
   /* ---- staging between struct bwt and a device block ---------------------- */
@@ -266,6 +304,36 @@ namespace bwt {
     fetch_block(res, c, h, mem, opt);
     stat.end(ts_event_bwt_leaf);
     return res;
+  }
+
+  /* The gap array of a merge (reference include/bwt.h:730-787): for every position j of r, g_j = l.a + the number
+     of l's suffixes below T[j:]; gap[g_j] is counted, r's samples get g added to their rank (r.ssa is left ordered
+     by position, as there), and the sparse prefix sums are set.  The LF chains and the histogram run on the device
+     (bwt_hip_gap, which leaves both blocks as they are); the counters and the g values come back to fill the caller's
+     gap_array.  `gap` has been initialised over [l.a, l.b]. */
+  inline int build_gap(bwt & l, bwt & r, gap_array & gap, mallocator & mem, bwt_opt & opt) {
+    stat.start(ts_event_bwt_build_gap);
+    assert(l.T == r.T && l.n == r.n && l.L == r.L && l.b == r.a);
+    check(gap.a == l.a && gap.b == l.b);
+    bwt_hip_ctx * c = device_session::get().with_text(l.T, l.n, opt.device);
+    bwt_hip_block * hl = device_block(l, c, mem);
+    bwt_hip_block * hr = device_block(r, c, mem);
+    const idx_t m = l.b - l.a, rn = r.b - r.a;
+    int64_t * counts = new int64_t[m + 1];
+    int64_t * g = new int64_t[rn];
+    bwt_hip_ok(bwt_hip_gap(c, hl, hr, opt.build_gap_segment_sz, counts, g));
+    for (idx_t i = 0; i <= m; i++)
+      if (counts[i]) gap.set_count(l.a + i, counts[i]);
+    r.ssa.sort_by_pos(mem);
+    for (ssa_iterator it = r.ssa.pos_begin(mem); it.has_next(); it.next()) it.e->rank += g[it.e->pos - r.a];
+    /* the device copy of r still holds the ranks as they were: it no longer describes r */
+    bwt_hip_block_free(c, hr);
+    r.dev = 0;
+    delete[] counts;
+    delete[] g;
+    gap.set_prefix_sum(mem, opt.prefix_sum_gran);
+    stat.end(ts_event_bwt_build_gap);
+    return 1;
   }
 
   /* merges the BWTs of T[a:c) and T[c:b) into the BWT of T[a:b); l and r are finished */

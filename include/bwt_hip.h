@@ -245,12 +245,13 @@ int bwt_hip_dist_wire_unpack(bwt_hip_ctx *ctx, const uint8_t *packed_dev, int64_
    the part placed before its left symbol i. */
 int bwt_hip_dist_merge_slice(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev, int64_t rn,
                              uint32_t *g_dev, uint8_t *out_dev, uint32_t *S_dev);
-/* bwt_hip_dist_merge_slice for callers that cannot allocate device memory (code under HIP graph capture, tight
-   serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results;
+/* bwt_hip_dist_merge_slice for callers that must not reach hipMalloc / hipFree (tight serving loops, harnesses
+   that forbid allocation).  No counterpart in the reference.  Same arguments and results;
    the scratch the kernels need (the histogram sort's second buffer, its tile counts and scan partials) lies in
-   a static device array that the library holds on every GPU it runs on (20 MiB, until the process ends)
-   instead of pool memory: the call reaches no hipMalloc / hipFree.  Limit: rn <= BWT_HIP_NOALLOC_MAX_RIGHT,
-   larger calls fail with BWT_HIP_EINVAL before any work.  Phase timers are not recorded for this call.  All calls
+   a static device array that the library holds on every GPU it runs on (24 MiB, until the process ends)
+   instead of pool memory: the call reaches no hipMalloc / hipFree.  Limit: rn <= BWT_HIP_NOALLOC_MAX_RIGHT for any
+   mL, larger calls fail with BWT_HIP_EINVAL before any work.  The call synchronises the context's stream (it is not
+   for use under HIP graph capture).  Phase timers are not recorded for this call.  All calls
    on one GPU share the array: two that overlap in time (two contexts or streams on one GPU) race. */
 #define BWT_HIP_NOALLOC_MAX_RIGHT 4194304
 int bwt_hip_dist_merge_slice_noalloc(bwt_hip_ctx *ctx, const uint8_t *lL_dev, int64_t mL, const uint8_t *rL_dev,

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdio.h>
 
 #include "typedefs.h"
 #include "util.h"
@@ -75,6 +76,33 @@ namespace bwt {
       overflow = 0;
       ps = 0;
       stat.end(ts_event_gap_array_fini);
+    }
+
+    /* debug listing (reference include/gap_array.h:70-90): the layout, then every non-zero byte counter and every
+       overflow entry in use */
+    void show() {
+      printf("range: [%ld,%ld] %ld elements\n", (long)a, (long)b, (long)(b - a + 1));
+      printf("overflow: %ld elements\n", (long)m);
+      printf("prefix sum: [%ld,%ld] %ld elements\n", (long)ps_a, (long)ps_b, (long)(ps_b - ps_a + 1));
+      printf("sum interval: %ld\n", (long)sum_interval);
+      if (small) {
+        printf("small:\n");
+        for (idx_t i = a; i <= b; i++)
+          if (small[i]) printf("%6ld : %d\n", (long)i, (int)small[i]);
+      }
+      if (overflow) {
+        printf("overflow:\n");
+        for (idx_t j = 0; j < m; j++)
+          if (overflow[j].i != -1) printf("%6ld : %ld %ld\n", (long)j, (long)overflow[j].i, (long)overflow[j].c);
+      }
+    }
+
+    /* Sets gap[i] = count for an index that is still 0 (a bulk fill from counts computed elsewhere; one thread). */
+    void set_count(idx_t i, idx_t count) {
+      assert(a <= i && i <= b && small[i] == 0);
+      if (count < 255) { small[i] = (uint8_t)count; return; }
+      overflow[overflow_slot(i, 1)].c = count - 255;
+      small[i] = 255;
     }
 
     /* the table slot of index i; claims a free one if `insert` (several threads may ask for the same i) */

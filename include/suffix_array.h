@@ -4,6 +4,7 @@
 #pragma once
 
 #include <assert.h>
+#include <stdio.h>
 
 #include "typedefs.h"
 #include "util.h"
@@ -31,6 +32,17 @@ namespace bwt {
     bwt_hip_ctx * c = device_session::get().with_text(T, n, mem.opt.device);
     bwt_hip_ok(bwt_hip_leaf_sa(c, a, b, (int64_t *)(SA + a)));
     return 1;
+  }
+
+  /* debug listing of SA[a:b) (reference include/suffix_array.h:67-81): rank, position, the symbol in front of
+     the suffix ('$' for the terminator) and the suffix itself, one line per rank */
+  inline void sa_show(const alpha_t * T, idx_t n, idx_t a, idx_t b, idx_t * SA) {
+    for (idx_t i = a; i < b; i++) {
+      const idx_t o = SA[i];
+      assert(o >= a && o < b);
+      const alpha_t p = o ? T[o - 1] : T[n - 1];
+      printf("%2lu %2lu %c %s\n", (unsigned long)i, (unsigned long)o, p ? p : '$', (const char *)(T + o));
+    }
   }
 
 }

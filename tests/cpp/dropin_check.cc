@@ -112,6 +112,62 @@ int main() {
     printf("OK sa_range, bwt_rec, sampled sa\n");
     delete[] T; delete[] L; delete[] I; delete[] SA;
   }
+  {  // build_gap and resample_sa called by hand (reference include/bwt.h:730-787, :366-453) against a direct count
+     // and against the samples the device merge keeps
+    bwt::idx_t n = 9000, a = 300, b = 8700, c = (a + b) / 2;
+    bwt::alpha_t * T = gen(n, 21, 4), * M = new bwt::alpha_t[n];
+    for (bwt::idx_t i = 4000; i < 4700; i++) T[i] = 3;  // a run across the boundary
+    for (bwt::idx_t i = 5000; i < 8000; i += 7) T[i] = 9;  // a symbol the left block lacks: its suffixes share the last gap index (a count above 254)
+    bwt::idx_t * SA = new bwt::idx_t[n];
+    bwt::bwt_opt opt;
+    opt.set_defaults();
+    opt.ssa_n_samples = 150;
+    opt.build_gap_segment_sz = 64;
+    bwt::mallocator mem(opt);
+    bwt::bwt l = bwt::bwt_leaf(T, n, a, c, M, mem, opt);
+    bwt::bwt r = bwt::bwt_leaf(T, n, c, b, M, mem, opt);
+    bwt::gap_array gap;
+    gap.init(l.a, l.b, mem, opt.gap_sum_gran);
+    if (!bwt::build_gap(l, r, gap, mem, opt)) return fail("build_gap");
+    bwt::sa_range(T, n, a, c, SA, mem);
+    bwt::idx_less lt(T, n);
+    bwt::idx_t * want = new bwt::idx_t[c - a + 1];
+    for (bwt::idx_t i = 0; i <= c - a; i++) want[i] = 0;
+    for (bwt::idx_t j = c; j < b; j++) {
+      bwt::idx_t lo = a, hi = c;  // first left rank whose suffix is above T[j:]
+      while (lo < hi) {
+        bwt::idx_t mid = (lo + hi) / 2;
+        if (lt(SA[mid], j)) lo = mid + 1; else hi = mid;
+      }
+      want[lo - a]++;
+    }
+    bwt::idx_t run = 0, big = 0;
+    for (bwt::idx_t i = a; i <= c; i++) {
+      if (gap.get(i) != want[i - a]) return fail("gap counts");
+      run += want[i - a];
+      if (gap.sum(i) != run) return fail("gap prefix sums");
+      if (want[i - a] > 254) big++;
+    }
+    if (run != b - c || big == 0) return fail("gap total / overflow path exercised");
+    bwt::bwt mh;
+    mh.init(T, n, M, a, b);
+    if (!mh.resample_sa(l.ssa, r.ssa, c, bwt::min(opt.ssa_n_samples, b - a), gap, mem, opt)) return fail("resample_sa");
+    gap.fini(mem);
+    // the device merge of the same two leaves
+    bwt::bwt l2 = bwt::bwt_leaf(T, n, a, c, M, mem, opt);
+    bwt::bwt r2 = bwt::bwt_leaf(T, n, c, b, M, mem, opt);
+    bwt::bwt md = bwt::bwt_merge(l2, r2, 0, mem, opt);
+    if (mh.s_rank != md.s_rank || mh.e_rank != md.e_rank) return fail("resample_sa special ranks");
+    if (mh.ssa.n != md.ssa.n) return fail("resample_sa sample count");
+    for (bwt::idx_t k = 0; k < md.ssa.sz; k++)
+      if (md.ssa.a[k].rank != -1 && mh.ssa.get(md.ssa.a[k].rank) != md.ssa.a[k].pos) return fail("resample_sa sample set");
+    l.fini(mem, opt);
+    r.fini(mem, opt);
+    mh.fini(mem, opt);
+    md.fini(mem, opt);
+    printf("OK build_gap and resample_sa by hand\n");
+    delete[] T; delete[] M; delete[] SA; delete[] want;
+  }
   printf("ALL OK\n");
   return 0;
 }

@@ -75,3 +75,17 @@ def test_bench_rejects_leaf_counts_that_do_not_fit_the_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--leaves", "2"], capture_output=True,
                        text=True, env=env)
     assert r.returncode == 2 and "multiple of the 4 GPUs" in r.stderr
+
+
+def test_bench_line_says_what_value_measures():
+    """`value` is the HBM-resident rate with the library's timers off; the host-to-host rate of bwt::pmbwt's own
+    call travels in the same line under `host_to_host`, over the same number of steps."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = bench.VALUE_DEFINITION
+    assert "resident in HBM" in d and "timers off" in d and "host_to_host" in d and "bwt_hip_pmbwt_host" in d
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "host_to_host(ctx, n, th, ns, args.seg, args.steps)" in src
+    assert src.index("ctx.set_timing(0)\n    dt = timed_builds") < src.index("ctx.set_timing(2)")

@@ -105,6 +105,35 @@ def _build(c, n, leaves, ns):
     return blk, L, r, p, info
 
 
+def _suffix_less(T, x, y):
+    """T[x:] < T[y:] by reading the text itself (x != y; the unique terminator ends it)."""
+    n = len(T)
+    step = 64
+    while True:
+        k = min(step, n - x, n - y)
+        a, b = T[x:x + k], T[y:y + k]
+        d = np.flatnonzero(a != b)
+        if len(d):
+            return bool(a[d[0]] < b[d[0]])
+        x, y, step = x + k, y + k, step * 4
+
+
+def _adjacent_ranks_increase(blk, T, L, count=2000, seed=1):
+    """The property the reference's own suffix array test checks (src/test/test_suffix_array.cc:27-48): for random
+    ranks r, the suffixes at SA[r] and SA[r+1] (positions looked up on the device) are compared by reading the host copy
+    of the text itself, and L[r] is the symbol in front of SA[r].  The verdict on the order comes from the text alone,
+    not from the rank structure that the chains and the device decoding share."""
+    n = len(T)
+    rng = np.random.RandomState(seed)
+    r = np.unique(np.concatenate([rng.randint(0, n - 1, size=count), [0, n - 2, blk.s_rank - 1 if blk.s_rank else 0]]))
+    r = r[(r >= 0) & (r < n - 1)].astype(np.int64)
+    pos = blk.sa(np.concatenate([r, r + 1]))
+    p0, p1 = pos[:len(r)], pos[len(r):]
+    assert (L[r] == T[p0 - 1]).all() and (L[r + 1] == T[p1 - 1]).all()
+    for x, y in zip(p0.tolist(), p1.tolist()):
+        assert x != y and _suffix_less(T, x, y), (x, y)
+
+
 def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves, sigma=4):
     ctx.set_timing(2)
     ctx.reset_timers()
@@ -116,8 +145,9 @@ def _full_size(ctx, n, leaves, ns, expect_variants, other_leaves, sigma=4):
     assert launches(ctx, "leaf:k_bucket_emit") == leaves and same_variants(got, expect_variants), got
     # decoded on the device, L gives the text back (src/pmbwt.cc:64-81 check_result)
     assert blk.ibwt_mismatches() == 0
-    blk.free()
     T = ctx.get_text()
+    _adjacent_ranks_increase(blk, T, L)
+    blk.free()
     # L is a permutation of T with the terminator at s_rank; every sample (rank, pos) has L[rank] = T[pos-1]
     assert (np.bincount(L, minlength=256) == np.bincount(T, minlength=256)).all()
     assert L[info[0]] == 0 and info[1] == 0 and info[2] == 0
@@ -262,6 +292,7 @@ def test_config4_repetitive_4_6e8(ctx):
     assert (np.bincount(L, minlength=5) == np.bincount(T, minlength=5)).all()
     assert L[blk.s_rank] == 0 and p[0] == 0 and p[-1] == n - 1
     assert (L[r] == T[p - 1]).all()
+    _adjacent_ranks_increase(blk, T, L)
     fnv = h8(L)
     blk.free()
     b4 = ctx.pmbwt(n // 4 + 1, 1000000)

@@ -92,6 +92,39 @@ def test_no_alloc_merge_slice_twice(ctx):
     one_call(ctx, hip, 0, 5000, 4)
 
 
+@pytest.mark.timeout(600)
+def test_no_alloc_largest_layout(ctx):
+    """The maximum right count next to a left part of more than 2^30 symbols: the grouping with the most buckets and
+    tiles, i.e. the most scratch the call can need.  Static against pool, and S against numpy."""
+    hip = Hip()
+    mL, rn = (1 << 30) + 12345, 4194304
+    rng = np.random.RandomState(9)
+    lL = rng.randint(1, 5, size=mL, dtype=np.uint8)
+    rL = rng.randint(1, 5, size=rn).astype(np.uint8)
+    g = rng.randint(0, mL + 1, size=rn).astype(np.uint32)
+    g[:1000] = mL  # the last gap index
+    g[1000:2000] = 0
+    want_S = np.cumsum(np.bincount(g, minlength=mL + 1), dtype=np.uint32)
+    d_l, d_r = hip.up(lL), hip.up(rL)
+    res = {}
+    for name, fn in (("pool", ctx.dist_merge_slice), ("static", ctx.dist_merge_slice_noalloc)):
+        d_g = hip.up(g)
+        d_out, d_S = hip.empty(mL + rn), hip.empty(4 * (mL + 1))
+        before = ctx.mem_stats()
+        fn(d_l, mL, d_r, rn, d_g, d_out, d_S)
+        after = ctx.mem_stats()
+        if name == "static":
+            assert after["reserved"] == before["reserved"] and after["peak"] == before["peak"]
+        res[name] = (hip.down(d_out, np.uint8, mL + rn), hip.down(d_S, np.uint32, mL + 1))
+    hip.free_all()
+    assert (res["static"][1] == want_S).all() and (res["pool"][1] == want_S).all()
+    assert (res["pool"][0] == res["static"][0]).all()
+    out = res["static"][0]
+    probe = rng.randint(0, mL, size=100000)  # left symbol i sits at i + S[i]
+    assert (out[probe + want_S[probe].astype(np.int64)] == lL[probe]).all()
+    assert (np.bincount(out, minlength=5) == np.bincount(lL, minlength=5) + np.bincount(rL, minlength=5)).all()
+
+
 def test_no_alloc_rejects_oversize(ctx):
     import bwt_amd
     hip = Hip()
