@@ -311,6 +311,9 @@ int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t th, int64_t ns, int64_t seg, bwt_hip
     g_last_error = "invalid argument: ctx";
     return BWT_HIP_EINVAL;
   }
+  // a build of the whole text starts from the text alone: what an earlier build derived from it (the ranks of its
+  // difference-cover sample) is made again if this one needs it
+  drop_dc_sample(ctx->c);
   return bwt_hip_rec(ctx, 0, ctx->c.n, th, ns, seg, out);
 }
 

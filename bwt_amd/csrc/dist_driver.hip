@@ -434,6 +434,7 @@ static std::unique_ptr<DistBlock> dist_build(Ctx &c, bwt_hip_transport *t, i64 t
   std::vector<std::pair<i64, i64>> ranges;
   split_ranges(0, c.n, depth, ranges);
   const i64 a = ranges[(size_t)me].first, b = ranges[(size_t)me].second;
+  drop_dc_sample(c);  // a build of the whole text starts from the text alone
   std::unique_ptr<Block> own(build_rec(c, a, b, th, ns, seg));
   std::unique_ptr<DistBlock> blk(new DistBlock());
   blk->a = a;

@@ -211,16 +211,20 @@ struct FirstListOut {
   u32 *slot, *pos, *grp;
   u32 *total;
   size_t n;
-  // not null: receives the size of the largest group (zeroed by the caller); mask = the key bits groups are made on
+  // not null: receives the size of the largest group above group_limit, if there is one (zeroed by the caller);
+  // mask = the key bits groups are made on
   u32 *max_group = nullptr;
   u64 mask = 0;
+  u32 group_limit = 0;
   __device__ __forceinline__ void operator()(size_t i, TieHead ex, TieHead in) const {
     if (in.cnt != ex.cnt) {
       u32 k = ex.cnt;
       slot[k] = (u32)i;
       pos[k] = v.pos(i);
       grp[k] = in.hmax - 1;
-      if (max_group && (i + 1 == n || (v.key(i + 1) & mask) != (v.key(i) & mask))) atomicMax(max_group, (u32)(i + 2 - in.hmax));
+      // (a plain store by the few groups above the limit: one atomic per group on one address would serialise them)
+      if (max_group && (u32)(i + 2 - in.hmax) > group_limit && (i + 1 == n || (v.key(i + 1) & mask) != (v.key(i) & mask)))
+        atomicMax(max_group, (u32)(i + 2 - in.hmax));
     }
     if (i + 1 == n) *total = in.cnt;
   }
@@ -1765,34 +1769,32 @@ constexpr int DT_THREADS = 256;
 constexpr int DT_TILE = 512;
 constexpr int DT_CAP = 1024;
 
-// X128: the packed symbols take more than 64 bits (short keys: small windows)
-template <class View, bool X128>
-__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0, u32 nx, u32 sbits, u32 min_sym) {
+// XW: 8-byte words of text staged per member (the symbols K0 .. K0 + 8 XW - 1 as they are in the text; first symbol =
+// lowest byte; 0 where the keys already cover v - 1 symbols).
+template <class View, int XW>
+__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0) {
   __shared__ u32 Rw[DT_CAP * DC_ND_MAX];  // first the entries' keys (two words each), then the windows of sample ranks
-  // the symbols K0 .. K0+nx-1 behind the position as codes of sbits bits (symbol - min_sym + 1; 0 = the terminator and
-  // beyond), first symbol in the highest bits of Xs, continued in Xl
-  __shared__ u64 Xs[DT_CAP];
-  __shared__ u64 Xl[X128 ? DT_CAP : 1];
+  __shared__ u64 Xw[XW ? DT_CAP * XW : 1];  // first the head scan's partial results
   __shared__ u32 Bp[DT_CAP];              // positions
   __shared__ u16 gs_s[DT_CAP], ge_s[DT_CAP];
-  __shared__ u16 meta[DT_CAP];            // position mod v; bit 8: the suffix ends inside its key
-  __shared__ u8 sym_s[DT_CAP];            // preceding symbol
-  __shared__ u16 tab_s[32 * 32];
-  __shared__ u32 tmx[DT_THREADS];
+  __shared__ u16 meta[DT_CAP];  // bits 0..4 position mod v; bit 5: the suffix ends inside its key; bits 8..15: preceding symbol
+  __shared__ u16 tab_s[31 * 31];
   __shared__ u32 scan_s[17];
   __shared__ u32 bounds[2];
+  __shared__ u32 tmx_own[XW ? 1 : DT_THREADS];
   static_assert(DT_CAP == 4 * DT_THREADS && DC_ND_MAX * 4 >= 8, "four entries per thread; the keys fit the rank windows");
   const u32 tid = threadIdx.x;
   const u64 base = (u64)blockIdx.x * DT_TILE;
   const u32 cnt = E.N - base < (u64)DT_CAP ? (u32)(E.N - base) : (u32)DT_CAP;
   u64 *keyb = reinterpret_cast<u64 *>(Rw);
+  u32 *tmx = XW ? reinterpret_cast<u32 *>(Xw) : tmx_own;
   const u64 prev_key = base ? (E.v.key(base - 1) & E.sym_mask) : 0ull;
   if (tid < 2) bounds[tid] = DT_CAP;
   for (u32 i = tid; i < dc.v * dc.v; i += DT_THREADS) tab_s[i] = dc.pair_tab[i];
   for (u32 i = tid; i < cnt; i += DT_THREADS) {
     const u64 k = E.v.key(base + i);
     keyb[i] = k & E.sym_mask;
-    sym_s[i] = (u8)k;
+    meta[i] = (u16)(((u32)k & 0xFFu) << 8);
     Bp[i] = E.v.pos(base + i);
   }
   __syncthreads();
@@ -1834,89 +1836,99 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
     if (i > lo && gs_s[i] == i) ge_s[gs_s[i - 1]] = (u16)i;
     if (i + 1 == hi) ge_s[gs_s[i]] = (u16)hi;
   }
-  __syncthreads();  // the keys are dead: their room takes the rank windows
-  // suffixes alone in their group are final; the others load what the comparisons need
+  __syncthreads();  // the keys and the scan's partial results are dead: their room takes the rank windows and the text
+  // Suffixes alone in their group are final; the others load what the comparisons need.  All of a thread's loads are
+  // issued before the first is used: they are random reads, and the pass lives on how many are in flight.
   const u8 *__restrict__ T = E.T;
+  u32 rk[4][DC_ND_MAX];
+  u64 xw[4][XW ? XW : 1];
+  bool tied[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 i = lo + tid + r * DT_THREADS;
+    tied[r] = false;
+    if (i >= hi) continue;
+    const u32 s = gs_s[i];
+    tied[r] = ge_s[s] - s > 1;
+    if (!tied[r]) continue;
+    const u32 p = Bp[i];
+    const u32 blk = p / dc.v, res = p - blk * dc.v;
+    meta[i] = (u16)((meta[i] & 0xFF00u) | res | ((u64)p + K0 >= E.n ? 0x20u : 0u));
+    const u32 k0 = blk * dc.nd + dc.lo_tab[res];
+#pragma unroll
+    for (u32 x = 0; x < DC_ND_MAX; x++) rk[r][x] = (x < dc.nd && k0 + x < dc.n_s) ? dc.rank[k0 + x] : 0u;
+    if constexpr (XW > 0) {
+      const u64 q = (u64)p + K0;
+      if (q + 8 * XW <= E.n) {
+#pragma unroll
+        for (int x = 0; x < XW; x++) __builtin_memcpy(&xw[r][x], T + q + 8 * x, 8);
+      } else {  // the end of the text: symbol by symbol, nothing beyond it
+#pragma unroll
+        for (int x = 0; x < XW; x++) {
+          u64 word = 0;
+          for (u32 y = 0; y < 8; y++)
+            if (q + 8 * x + y < E.n) word |= (u64)T[q + 8 * x + y] << (8 * y);
+          xw[r][x] = word;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const u32 i = lo + tid + r * DT_THREADS;
     if (i >= hi) continue;
-    const u32 s = gs_s[i], t = ge_s[s];
-    const u32 p = Bp[i];
-    if (t - s == 1) {
-      E.place(base + i, p, sym_s[i]);
+    if (!tied[r]) {
+      E.place(base + i, Bp[i], (u32)meta[i] >> 8);
       continue;
     }
-    const u32 blk = p / dc.v, res = p - blk * dc.v;
-    meta[i] = (u16)(res | ((u64)p + K0 >= E.n ? 0x100u : 0u));
-    const u32 k0 = blk * dc.nd + dc.lo_tab[res];
-    for (u32 x = 0; x < dc.nd; x++) Rw[i * DC_ND_MAX + x] = k0 + x < dc.n_s ? dc.rank[k0 + x] : 0u;
-    u64 xh = 0, xl = 0;
-    const u64 q = (u64)p + K0;
-    for (u32 x = 0; x < nx; x++) {
-      const u32 ch = q + x < E.n ? T[q + x] : 0u;
-      const u64 code = ch ? (u64)(ch - min_sym + 1u) : 0ull;
-      const u32 at = (x + 1) * sbits;  // the code's lowest bit lies `at` bits below the top of the 128
-      if (at <= 64) xh |= code << (64 - at);
-      else if (X128) {
-        xl |= code << (128 - at);
-        if (at - sbits < 64) xh |= code >> (at - 64);  // a code across the two words
-      }
+#pragma unroll
+    for (u32 x = 0; x < DC_ND_MAX; x++) Rw[i * DC_ND_MAX + x] = rk[r][x];
+    if constexpr (XW > 0) {
+#pragma unroll
+      for (int x = 0; x < XW; x++) Xw[i * XW + x] = xw[r][x];
     }
-    Xs[i] = xh;
-    if (X128) Xl[i] = xl;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const u32 i = lo + tid + r * DT_THREADS;
-    if (i >= hi) continue;
+    if (i >= hi || !tied[r]) continue;
     const u32 s = gs_s[i], t = ge_s[s];
-    if (t - s == 1) continue;
-    const u32 mi = meta[i], ri = mi & 0xFFu, pi = Bp[i];
-    const bool short_i = (mi & 0x100u) != 0;
-    const u64 xi = Xs[i], xli = X128 ? Xl[i] : 0ull;
+    const u32 mi = meta[i], ri = mi & 31u, pi = Bp[i];
+    const bool short_i = (mi & 0x20u) != 0;
     const u16 *row = tab_s + ri * dc.v;
     const u32 *mine = Rw + i * DC_ND_MAX;
     u32 below = 0;
+    // No branch on the pair inside the loop (its iterations then overlap their LDS look-ups): the ranks decide unless the
+    // staged symbols differ before the shift d.  Entry i against itself comes out "not below" by the same arithmetic.
+#pragma unroll 4
     for (u32 j = s; j < t; j++) {
-      if (j == i) continue;
       const u32 mj = meta[j];
-      bool less;  // is the suffix of entry j below that of entry i?
-      if ((mj | mi) & 0x100u) {
-        // a suffix that ends inside its key is below every longer one with the same key; of two such the shorter
-        const bool short_j = (mj & 0x100u) != 0;
-        less = short_j && (!short_i || Bp[j] > pi);
-      } else {
-        const u32 e = row[mj & 0xFFu];
-        const u32 d = e & 31u;
-        bool decided = false;
-        less = false;
-        if (d > K0) {
-          const u32 nb = (d - K0) * sbits;  // the leading bits that hold the symbols K0 .. d-1
-          const u64 xj = Xs[j];
-          if (!X128 || nb <= 64) {
-            const u64 a = xi >> (64 - nb), b = xj >> (64 - nb);
-            if (a != b) {
-              less = b < a;
-              decided = true;
-            }
-          } else if (xi != xj) {
-            less = xj < xi;
-            decided = true;
-          } else {
-            const u64 a = xli >> (128 - nb), b = Xl[j] >> (128 - nb);
-            if (a != b) {
-              less = b < a;
-              decided = true;
-            }
+      const u32 e = row[mj & 31u];
+      const u32 d = e & 31u;
+      bool less = Rw[j * DC_ND_MAX + ((e >> 9) & 15u)] < mine[(e >> 5) & 15u];  // is the suffix of entry j below that of entry i?
+      if constexpr (XW > 0) {
+        const u32 nb = d > K0 ? d - K0 : 0u;  // symbols K0 .. d-1: the first nb bytes of the staged words
+        u32 fd = 8 * XW;                      // first byte in which the two differ
+        u64 da = 0, db = 0;                   // the words that hold it
+#pragma unroll
+        for (int x = XW - 1; x >= 0; x--) {
+          const u64 a = xw[r][x], b = Xw[j * XW + x];
+          if (a != b) {
+            fd = 8 * x + ((u32)__builtin_ctzll(a ^ b) >> 3);
+            da = a;
+            db = b;
           }
         }
-        if (!decided) less = Rw[j * DC_ND_MAX + ((e >> 9) & 15u)] < mine[(e >> 5) & 15u];
+        if (fd < nb) less = ((db >> (8 * (fd & 7u))) & 0xFFu) < ((da >> (8 * (fd & 7u))) & 0xFFu);
+      }
+      if (__builtin_expect(((mj | mi) & 0x20u) != 0, 0)) {
+        // a suffix that ends inside its key is below every longer one with the same key; of two such the shorter
+        less = (mj & 0x20u) != 0 && (!short_i || Bp[j] > pi);
       }
       below += less;
     }
-    E.place(base + s + below, pi, sym_s[i]);
+    E.place(base + s + below, pi, mi >> 8);
   }
 }
 
@@ -2016,7 +2028,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     u32 *d_maxg = c.d_scalars + 11;
     HIP_CHECK(hipMemsetAsync(d_maxg, 0, sizeof(u32), c.stream));
     scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<View>{v, N, sym_mask},
-                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N, d_maxg, sym_mask});
+                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N, d_maxg, sym_mask, (u32)(DT_CAP - DT_TILE + 1)});
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, d_total, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 11, d_maxg, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
     c.sync();
@@ -2038,13 +2050,7 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
     }
     if (wanted) {
       ensure_dc_sample(c);
-      const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
-      const u32 xbits = (u32)bits_for((u64)(c.max_sym - (int)min_sym + 1));  // codes symbol - min_sym + 1
-      const u32 nx = c.dc.v - 1 > (u32)K0 ? c.dc.v - 1 - (u32)K0 : 0u;
-      if (nx * xbits > 128) {
-        *redo = REDO_NO_DC;
-        return false;
-      }
+      const u32 nx = c.dc.v - 1 > (u32)K0 ? c.dc.v - 1 - (u32)K0 : 0u;  // symbols behind the key that a comparison may need
       Phase ph(c, "leaf_dc_emit", (double)N * (e_w ? 8 : 12) + (double)M * (c.dc.nd * 4 + nx) + (double)(b - a) * 2);
       LeafEmit<View> em;
       memset(&em, 0, sizeof(em));
@@ -2062,8 +2068,10 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
       HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
       const DcView dv{c.dc.rank, c.dc.pair_tab, c.dc.lo_tab, c.dc.v, c.dc.nd, c.dc.n_s};
       const dim3 grid(ceil_div(N, DT_TILE)), block(DT_THREADS);
-      if (nx * xbits > 64) hipLaunchKernelGGL((k_dc_emit<View, true>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym);
-      else hipLaunchKernelGGL((k_dc_emit<View, false>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym);
+      if (nx == 0) hipLaunchKernelGGL((k_dc_emit<View, 0>), grid, block, 0, c.stream, em, dv, (u32)K0);
+      else if (nx <= 8) hipLaunchKernelGGL((k_dc_emit<View, 1>), grid, block, 0, c.stream, em, dv, (u32)K0);
+      else if (nx <= 16) hipLaunchKernelGGL((k_dc_emit<View, 2>), grid, block, 0, c.stream, em, dv, (u32)K0);
+      else hipLaunchKernelGGL((k_dc_emit<View, 4>), grid, block, 0, c.stream, em, dv, (u32)K0);
       HIP_CHECK(hipGetLastError());
       if (read_u32(c, d_fail) != 0) {
         *redo = REDO_NO_DC;
@@ -2292,7 +2300,7 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
-static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out, int dc_state, int *redo) {
+static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out, bool repeats, int dc_state, int *redo) {
   const u64 N = (u64)(e - a);
   const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
   const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
@@ -2303,8 +2311,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   const int begin_bit = low_bit & ~7;  // whole digits; the extra low bits are zero padding
   const int passes = (64 - begin_bit) / 8;
   TextKeys tk{c.T, (u64)c.n, (u64)a, kp.w, K0, min_sym, kp.one_based, kp.pbits};
-  // a text with long repeats goes straight to the plain passes and the refinement rounds
-  const bool repeats = window_has_long_repeats(c, a, N);
+  // (repeats: a text with long repeats goes straight to the plain passes and what follows them)
   // Large windows: lean elements; wide ones where those do not apply.  These routes settle every tie on the text
   // itself, so they sort the leaf's own suffixes and no window slack.  (force_wide 3: never the lean route; windows
   // the packed elements can index then take those elements' own bucket route, the lean route's predecessor.)
@@ -2377,12 +2384,17 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   // A text whose sample ranks exist (an earlier leaf found it repetitive) is sorted leaf by leaf without slack: ties
   // are settled by those ranks, which are the whole text's.
   int dc_state = (c.dc_mode > 0 && c.dc.valid) ? 1 : 0;
+  // a large leaf is probed for long repeats: such a text skips the bucket routes and the direct pass, and, where the
+  // sample ranks may be used, is sorted without slack from the start
+  c.wait_text((u64)b + 128);
+  const bool repeats = window_has_long_repeats(c, a, (u64)(b - a));
+  if (repeats && c.dc_mode > 0) dc_state = 1;
   for (;;) {
     const i64 e = dc_state == 1 ? b : b + slack;
     // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it
     c.wait_text((u64)e + DF_DEPTH + 128);
     int redo = 0;
-    if (sort_window(c, a, b, e, E, sa_out, dc_state, &redo)) return;
+    if (sort_window(c, a, b, e, E, sa_out, repeats, dc_state, &redo)) return;
     if (redo == REDO_DC) {
       dc_state = 1;
       continue;
