@@ -49,6 +49,9 @@ struct ChainParams {
   // and periods; suffix_less steps over them
   const u32 *runs;
   u32 n_runs;
+  // ranks of the text's difference-cover sample, where a leaf has made them (rank == null otherwise): comparisons then
+  // read at most v symbols
+  DcView dc;
 };
 
 // The listed stretch (start, end, period p: T[j] = T[j-p] for start + p <= j < end) that holds x with at least its
@@ -107,7 +110,48 @@ __device__ __forceinline__ bool suffix_less(const u8 *__restrict__ T, u64 n, u64
   }
 }
 
+// The same with the ranks of a difference-cover sample: the one shift d < v that makes x + d and y + d sample positions
+// comes from a table; the suffixes compare on their first d symbols and then on the two ranks.
+__device__ __forceinline__ bool suffix_less_dc(const u8 *__restrict__ T, u64 n, u64 x, u64 y, const DcView &dc) {
+  const u32 bx = (u32)x / dc.v, rx = (u32)x - bx * dc.v;
+  const u32 by = (u32)y / dc.v, ry = (u32)y - by * dc.v;
+  const u32 d = dc.pair_tab[rx * dc.v + ry] & 31u;
+  u32 k = 0;
+  while (k < d) {
+    if (x + k + 8 <= n && y + k + 8 <= n) {
+      u64 wx, wy;
+      __builtin_memcpy(&wx, T + x + k, 8);
+      __builtin_memcpy(&wy, T + y + k, 8);
+      if (wx != wy) {
+        const u32 at = (u32)__builtin_ctzll(wx ^ wy) >> 3;
+        if (k + at >= d) break;  // the first difference lies behind the shift: the ranks decide
+        return ((wx >> (8 * at)) & 0xFFu) < ((wy >> (8 * at)) & 0xFFu);
+      }
+      k += 8;
+    } else {  // near the end of the text: the unique terminator ends this at the latest
+      const u32 cx = T[x + k], cy = T[y + k];
+      if (cx != cy) return cx < cy;
+      k++;
+    }
+  }
+  // d equal symbols, none of them the terminator: both shifted positions are below n
+  u32 sx = rx + d, sy = ry + d, kx = bx, ky = by;
+  if (sx >= dc.v) {
+    sx -= dc.v;
+    kx++;
+  }
+  if (sy >= dc.v) {
+    sy -= dc.v;
+    ky++;
+  }
+  return dc.rank[kx * dc.nd + dc.lo_tab[sx]] < dc.rank[ky * dc.nd + dc.lo_tab[sy]];
+}
+
 constexpr int CHAIN_THREADS = 256;
+
+__device__ __forceinline__ bool chain_suffix_less(const ChainParams &P, u64 x, u64 y) {
+  return P.dc.rank ? suffix_less_dc(P.T, P.n, x, y, P.dc) : suffix_less(P.T, P.n, x, y, P.runs, P.n_runs);
+}
 
 // Backward sequential reader of the text.  A chain's text positions are 1024 bytes away from its
 // neighbours', so a byte load per step would touch a different cache line in every lane and find it
@@ -152,7 +196,7 @@ __device__ __forceinline__ u64 chain_interval(const ChainParams &P, const u32 *b
     u32 klo = wm_lf(P.wm, base_s, c, lo);
     u32 khi = (hi == lo) ? klo : wm_lf(P.wm, base_s, c, hi);
     if (c == e_char && khi >= e_rank) {
-      if (suffix_less(T, P.n, P.lb - 1, j, P.runs, P.n_runs)) {
+      if (chain_suffix_less(P, P.lb - 1, j)) {
         klo += (klo >= e_rank);
         khi += 1;
       }
@@ -210,7 +254,7 @@ __device__ __forceinline__ void chain_walk(const ChainParams &P, const u32 *base
       // kk counts the left suffixes below T[j:] other than the block's last one, T[lb-1:], whose rank is e_rank: more
       // than e_rank of them means that one is below T[j:] too; exactly e_rank leaves it to a comparison
       if (sym == e_char && kk >= e_rank) {
-        if (kk > e_rank || suffix_less(T, P.n, P.lb - 1, j0 - step, P.runs, P.n_runs)) kk++;
+        if (kk > e_rank || chain_suffix_less(P, P.lb - 1, j0 - step)) kk++;
       }
       g = kk;
     }
@@ -258,7 +302,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains_deferred(ChainParams P
   while (lo < hi) {
     const u32 mid = lo + (hi - lo) / 2;
     const u64 p = left_sa(P, base_s, mid);
-    if (suffix_less(P.T, P.n, p + len, j0 + len, P.runs, P.n_runs)) lo = mid + 1;
+    if (chain_suffix_less(P, p + len, j0 + len)) lo = mid + 1;
     else hi = mid;
   }
   chain_walk(P, base_s, text, chain, begin, j0, lo);
@@ -699,6 +743,7 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
   P.ns = 0;
   P.runs = c.runs;
   P.n_runs = c.n_runs;
+  P.dc = dc_view(c);
   if (l.n_samp > 0 && c.defer_chains) {
     defer_list = DBuf<u32>(c, lay.n_chains);
     P.defer_list = defer_list.get();

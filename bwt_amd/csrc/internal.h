@@ -359,6 +359,20 @@ struct Block {
   i64 len() const { return b - a; }
 };
 
+// What device code needs of Ctx::dc to compare two suffixes in at most v symbols and two look-ups (rank == null:
+// there is no sample).  pair_tab[(i mod v) * v + (j mod v)]: bits 0..4 = the shift d that makes i + d and j + d
+// sample positions, bits 5..8 / 9..12 = the sample positions in [i, i + d) / [j, j + d).  The compact index of a
+// sample position p is (p / v) * nd + lo_tab[p mod v].
+struct DcView {
+  const u32 *rank;
+  const u16 *pair_tab;
+  const u8 *lo_tab;
+  u32 v, nd, n_s;
+};
+static inline DcView dc_view(const Ctx &c) {
+  if (!c.dc.valid) return DcView{nullptr, nullptr, nullptr, 0, 0, 0};
+  return DcView{c.dc.rank, c.dc.pair_tab, c.dc.lo_tab, c.dc.v, c.dc.nd, c.dc.n_s};
+}
 // suffix_sort.hip: the ranks of the text's difference-cover sample (Ctx::dc), built on first use; the whole text must
 // have arrived.  drop_dc_sample releases them (a new text).
 void ensure_dc_sample(Ctx &c);

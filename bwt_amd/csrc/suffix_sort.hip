@@ -1749,13 +1749,6 @@ void ensure_dc_sample(Ctx &c) {
   dc.valid = true;
 }
 
-struct DcView {
-  const u32 *rank;
-  const u16 *pair_tab;
-  const u8 *lo_tab;
-  u32 v, nd, n_s;
-};
-
 // One pass from the window sorted on its first K0 symbols to the leaf's BWT, ties settled by the sample ranks.  The
 // window is the leaf itself (no slack: the ranks are those of the whole text).  A workgroup takes the groups of equal
 // keys that START in its DT_TILE window ranks (a group's members are consecutive), at most DT_CAP entries.  A suffix
@@ -1765,29 +1758,34 @@ struct DcView {
 // both p + d and q + d sample positions; the suffixes agree on their first K0 symbols, compare on the symbols K0 .. d-1
 // from the packed words, and then on the two ranks.  A group that does not fit raises *fail (the caller has checked
 // the largest group beforehand).
-constexpr int DT_THREADS = 256;
+constexpr int DT_THREADS = 512;
 constexpr int DT_TILE = 512;
 constexpr int DT_CAP = 1024;
+constexpr int DT_EPT = DT_CAP / DT_THREADS;  // entries per thread
 
-// XW: 8-byte words of text staged per member (the symbols K0 .. K0 + 8 XW - 1 as they are in the text; first symbol =
-// lowest byte; 0 where the keys already cover v - 1 symbols).
-template <class View, int XW>
-__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0) {
+// XW: 8-byte words of text read per member (the symbols K0 .. K0 + 8 XW - 1 as they are in the text; first symbol =
+// lowest byte; 0 where the keys already cover v - 1 symbols).  PK: the nx symbols that count are packed into one word
+// as codes of xbits bits (symbol - min_sym + 1; 0 = the terminator and beyond), first symbol highest, above six bits
+// that hold the position mod v and the "ends inside its key" flag: a pair then costs one 8-byte look-up for the other
+// member's symbols and flags, one shift and one compare for their common prefix.  Needs nx * xbits <= 58.
+template <class View, int XW, bool PK>
+__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0, u32 nx, u32 xbits, u32 min_sym) {
+  constexpr int XS = PK ? 1 : XW;         // words staged per member
   __shared__ u32 Rw[DT_CAP * DC_ND_MAX];  // first the entries' keys (two words each), then the windows of sample ranks
-  __shared__ u64 Xw[XW ? DT_CAP * XW : 1];  // first the head scan's partial results
+  __shared__ u64 Xw[XS ? DT_CAP * XS : 1];  // first the head scan's partial results
   __shared__ u32 Bp[DT_CAP];              // positions
   __shared__ u16 gs_s[DT_CAP], ge_s[DT_CAP];
   __shared__ u16 meta[DT_CAP];  // bits 0..4 position mod v; bit 5: the suffix ends inside its key; bits 8..15: preceding symbol
   __shared__ u16 tab_s[31 * 31];
   __shared__ u32 scan_s[17];
   __shared__ u32 bounds[2];
-  __shared__ u32 tmx_own[XW ? 1 : DT_THREADS];
-  static_assert(DT_CAP == 4 * DT_THREADS && DC_ND_MAX * 4 >= 8, "four entries per thread; the keys fit the rank windows");
+  __shared__ u32 tmx_own[XS ? 1 : DT_THREADS];
+  static_assert(DT_CAP == DT_EPT * DT_THREADS && DC_ND_MAX * 4 >= 8 && (!PK || XW > 0), "the keys fit the rank windows");
   const u32 tid = threadIdx.x;
   const u64 base = (u64)blockIdx.x * DT_TILE;
   const u32 cnt = E.N - base < (u64)DT_CAP ? (u32)(E.N - base) : (u32)DT_CAP;
   u64 *keyb = reinterpret_cast<u64 *>(Rw);
-  u32 *tmx = XW ? reinterpret_cast<u32 *>(Xw) : tmx_own;
+  u32 *tmx = XS ? reinterpret_cast<u32 *>(Xw) : tmx_own;
   const u64 prev_key = base ? (E.v.key(base - 1) & E.sym_mask) : 0ull;
   if (tid < 2) bounds[tid] = DT_CAP;
   for (u32 i = tid; i < dc.v * dc.v; i += DT_THREADS) tab_s[i] = dc.pair_tab[i];
@@ -1813,11 +1811,11 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
       return;
     }
   }
-  // first index of every entry's group: running maximum of the head indices; thread t owns entries 4t .. 4t+3
-  u32 hv[4], mx = 0;
+  // first index of every entry's group: running maximum of the head indices; thread t owns entries EPT t .. EPT t + EPT - 1
+  u32 hv[DT_EPT], mx = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u32 i = tid * 4 + j;
+  for (int j = 0; j < DT_EPT; j++) {
+    const u32 i = tid * DT_EPT + j;
     hv[j] = (i >= lo && i < hi && is_head(i)) ? i + 1 : 0u;
     mx = mx > hv[j] ? mx : hv[j];
   }
@@ -1826,8 +1824,8 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
   __syncthreads();
   u32 run = tid ? tmx[tid - 1] : 0u;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u32 i = tid * 4 + j;
+  for (int j = 0; j < DT_EPT; j++) {
+    const u32 i = tid * DT_EPT + j;
     run = run > hv[j] ? run : hv[j];
     if (i >= lo && i < hi) gs_s[i] = (u16)(run - 1);
   }
@@ -1840,11 +1838,11 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
   // Suffixes alone in their group are final; the others load what the comparisons need.  All of a thread's loads are
   // issued before the first is used: they are random reads, and the pass lives on how many are in flight.
   const u8 *__restrict__ T = E.T;
-  u32 rk[4][DC_ND_MAX];
-  u64 xw[4][XW ? XW : 1];
-  bool tied[4];
+  u32 rk[DT_EPT][DC_ND_MAX];
+  u64 xw[DT_EPT][XW ? XW : 1];
+  bool tied[DT_EPT];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < DT_EPT; r++) {
     const u32 i = lo + tid + r * DT_THREADS;
     tied[r] = false;
     if (i >= hi) continue;
@@ -1873,9 +1871,11 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
       }
     }
   }
+  u64 pk[DT_EPT];  // PK: this thread's own packed words
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < DT_EPT; r++) {
     const u32 i = lo + tid + r * DT_THREADS;
+    pk[r] = 0;
     if (i >= hi) continue;
     if (!tied[r]) {
       E.place(base + i, Bp[i], (u32)meta[i] >> 8);
@@ -1883,14 +1883,27 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
     }
 #pragma unroll
     for (u32 x = 0; x < DC_ND_MAX; x++) Rw[i * DC_ND_MAX + x] = rk[r][x];
-    if constexpr (XW > 0) {
+    if constexpr (PK) {
+      u64 word = meta[i] & 0x3Fu;
+      u32 at = 64;
+#pragma unroll
+      for (int x = 0; x < 8 * XW; x++) {
+        if ((u32)x < nx) {
+          const u32 ch = (u32)(xw[r][x >> 3] >> (8 * (x & 7))) & 0xFFu;
+          at -= xbits;
+          word |= (u64)(ch ? ch - min_sym + 1u : 0u) << at;
+        }
+      }
+      pk[r] = word;
+      Xw[i] = word;
+    } else if constexpr (XW > 0) {
 #pragma unroll
       for (int x = 0; x < XW; x++) Xw[i * XW + x] = xw[r][x];
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < DT_EPT; r++) {
     const u32 i = lo + tid + r * DT_THREADS;
     if (i >= hi || !tied[r]) continue;
     const u32 s = gs_s[i], t = ge_s[s];
@@ -1903,14 +1916,25 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
     // staged symbols differ before the shift d.  Entry i against itself comes out "not below" by the same arithmetic.
 #pragma unroll 4
     for (u32 j = s; j < t; j++) {
-      const u32 mj = meta[j];
+      u32 mj;
+      u64 xj = 0;
+      if constexpr (PK) {
+        xj = Xw[j];
+        mj = (u32)xj & 0x3Fu;
+      } else {
+        mj = meta[j];
+      }
       const u32 e = row[mj & 31u];
       const u32 d = e & 31u;
       bool less = Rw[j * DC_ND_MAX + ((e >> 9) & 15u)] < mine[(e >> 5) & 15u];  // is the suffix of entry j below that of entry i?
-      if constexpr (XW > 0) {
-        const u32 nb = d > K0 ? d - K0 : 0u;  // symbols K0 .. d-1: the first nb bytes of the staged words
-        u32 fd = 8 * XW;                      // first byte in which the two differ
-        u64 da = 0, db = 0;                   // the words that hold it
+      const u32 nb = d > K0 ? d - K0 : 0u;  // the symbols K0 .. d-1 have to agree before the ranks count
+      if constexpr (PK) {
+        const u32 sh = 64u - nb * xbits;  // at least 6
+        const u64 a = nb ? pk[r] >> sh : 0ull, b = nb ? xj >> sh : 0ull;
+        less = b < a || (b == a && less);
+      } else if constexpr (XW > 0) {
+        u32 fd = 8 * XW;     // first byte in which the two differ
+        u64 da = 0, db = 0;  // the words that hold it
 #pragma unroll
         for (int x = XW - 1; x >= 0; x--) {
           const u64 a = xw[r][x], b = Xw[j * XW + x];
@@ -2066,12 +2090,18 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
       em.T = c.T;
       em.n = (u64)c.n;
       HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
-      const DcView dv{c.dc.rank, c.dc.pair_tab, c.dc.lo_tab, c.dc.v, c.dc.nd, c.dc.n_s};
+      const DcView dv = dc_view(c);
       const dim3 grid(ceil_div(N, DT_TILE)), block(DT_THREADS);
-      if (nx == 0) hipLaunchKernelGGL((k_dc_emit<View, 0>), grid, block, 0, c.stream, em, dv, (u32)K0);
-      else if (nx <= 8) hipLaunchKernelGGL((k_dc_emit<View, 1>), grid, block, 0, c.stream, em, dv, (u32)K0);
-      else if (nx <= 16) hipLaunchKernelGGL((k_dc_emit<View, 2>), grid, block, 0, c.stream, em, dv, (u32)K0);
-      else hipLaunchKernelGGL((k_dc_emit<View, 4>), grid, block, 0, c.stream, em, dv, (u32)K0);
+      const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+      const u32 xbits = (u32)bits_for((u64)(c.max_sym - (int)min_sym + 1));  // codes symbol - min_sym + 1
+      const bool pk = nx > 0 && nx * xbits <= 58;
+#define DC_EMIT(XW, PK) hipLaunchKernelGGL((k_dc_emit<View, XW, PK>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym)
+      if (nx == 0) DC_EMIT(0, false);
+      else if (nx <= 8) { if (pk) DC_EMIT(1, true); else DC_EMIT(1, false); }
+      else if (nx <= 16) { if (pk) DC_EMIT(2, true); else DC_EMIT(2, false); }
+      else if (nx <= 24 && pk) DC_EMIT(3, true);
+      else DC_EMIT(4, false);
+#undef DC_EMIT
       HIP_CHECK(hipGetLastError());
       if (read_u32(c, d_fail) != 0) {
         *redo = REDO_NO_DC;
