@@ -67,6 +67,7 @@ def lib():
         "bwt_hip_block_rank": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_block_LF": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
+        "bwt_hip_dc_sample": [vp, i64, _i64p, _i64p, _i64p, C.POINTER(i32)],
         "bwt_hip_block_ibwt": [vp, vp, _u8p, _i64p],
         "bwt_hip_block_sa": [vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dist_bounds": [i64, i32, _i64p],
@@ -339,6 +340,16 @@ class Context:
         SA = np.empty(b - a, dtype=np.int64)
         _chk(lib().bwt_hip_leaf_sa(self._h, a, b, _p(SA, _i64p)))
         return SA
+
+    def dc_sample(self):
+        """(period, positions, ranks) of the text's difference-cover sample: ranks[k] = rank of T[positions[k]:] among
+        the sampled suffixes (built if it does not exist yet)."""
+        n_out, period = C.c_int64(0), C.c_int32(0)
+        _chk(lib().bwt_hip_dc_sample(self._h, 0, None, None, C.byref(n_out), C.byref(period)))
+        pos = np.empty(n_out.value, dtype=np.int64)
+        rank = np.empty(n_out.value, dtype=np.int64)
+        _chk(lib().bwt_hip_dc_sample(self._h, n_out.value, _p(pos, _i64p), _p(rank, _i64p), None, None))
+        return period.value, pos, rank
 
     def gap(self, l, r, build_gap_segment_sz=0, want_gap=True, want_g=True):
         gap = np.empty(l.b - l.a + 1, dtype=np.int64) if want_gap else None

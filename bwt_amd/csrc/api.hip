@@ -789,6 +789,27 @@ int bwt_hip_block_sa(bwt_hip_ctx *ctx, bwt_hip_block *blk_, int64_t nq, const in
   API_END
 }
 
+int bwt_hip_dc_sample(bwt_hip_ctx *ctx, int64_t cap, int64_t *pos_out, int64_t *rank_out, int64_t *n_out, int *period) {
+  API_BEGIN
+  need(ctx != nullptr && cap >= 0, "ctx, cap >= 0");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  HIP_CHECK(hipSetDevice(c.device));
+  ensure_dc_sample(c);
+  if (n_out) *n_out = c.dc.n_s;
+  if (period) *period = (int)c.dc.v;
+  const i64 k = (i64)c.dc.n_s < cap ? (i64)c.dc.n_s : cap;
+  if (k > 0 && rank_out) {
+    std::vector<u32> h((size_t)k);
+    HIP_CHECK(hipMemcpyAsync(h.data(), c.dc.rank, (size_t)k * 4, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    for (i64 i = 0; i < k; i++) rank_out[i] = (i64)h[(size_t)i];
+  }
+  if (pos_out)
+    for (i64 i = 0; i < k; i++) pos_out[i] = (i / c.dc.nd) * (i64)c.dc.v + (i64)c.dc.D[i % c.dc.nd];
+  API_END
+}
+
 int bwt_hip_gap(bwt_hip_ctx *ctx, bwt_hip_block *l_, bwt_hip_block *r_, int64_t seg, int64_t *gap_out,
                 int64_t *g_out) {
   API_BEGIN

@@ -182,7 +182,6 @@ struct TextBack {
 // ranks lo .. hi-1 share with T[j0:].
 __device__ __forceinline__ u64 chain_interval(const ChainParams &P, const u32 *base_s, TextBack &text, u64 j0, u64 ell,
                                               u32 *lo_out, u32 *hi_out) {
-  const u8 *__restrict__ T = P.T;
   const u32 e_char = P.e_char, e_rank = P.e_rank;
   u64 E = j0 + 1 + ell;
   if (E > P.n) E = P.n;
@@ -243,7 +242,6 @@ __device__ __forceinline__ u64 left_sa(const ChainParams &P, const u32 *base_s, 
 // the chain's positions below its last one: LF steps from the head's rank g
 __device__ __forceinline__ void chain_walk(const ChainParams &P, const u32 *base_s, TextBack &text, u32 chain, u64 begin,
                                            u64 j0, u32 g) {
-  const u8 *__restrict__ T = P.T;
   const u32 e_char = P.e_char, e_rank = P.e_rank;
   P.g[chain] = g;
   for (u32 step = 1; step < P.seg; step++) {
@@ -291,7 +289,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_chains_deferred(ChainParams P
   __syncthreads();
   const u32 t = blockIdx.x * CHAIN_THREADS + threadIdx.x;
   if (t >= count) return;
-  const u32 chain = P.defer_list[t];
+  const u32 chain = P.defer_list ? P.defer_list[t] : t;  // no list: every chain of the merge
   const u64 begin = P.ra + (u64)chain * P.seg;
   const u64 end = (begin + P.seg < P.rb) ? begin + P.seg : P.rb;
   const u64 j0 = end - 1;
@@ -744,21 +742,27 @@ ChainLayout run_chains(Ctx &c, Block &l, i64 ra, i64 rb, i64 seg_req, DBuf<u32> 
   P.runs = c.runs;
   P.n_runs = c.n_runs;
   P.dc = dc_view(c);
-  if (l.n_samp > 0 && c.defer_chains) {
+  // A text whose sample ranks exist has been found repetitive by its leaves: its chains' heads will not come out of a
+  // short backward search, so all of them go the second way at once.
+  const bool all_second = c.dc.valid && l.n_samp > 0 && c.defer_chains;
+  if (l.n_samp > 0 && c.defer_chains && !all_second) {
     defer_list = DBuf<u32>(c, lay.n_chains);
     P.defer_list = defer_list.get();
     HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
   }
-  {
+  if (!all_second) {
     // 64-byte random reads: one rank block per level and step, one 16-byte text block every 16 steps
     Phase ph(c, "gap_chains", (double)rn * l.wm.levels + (double)rn / 16);
     hipLaunchKernelGGL(k_chains, dim3(ceil_div(lay.n_chains, CHAIN_THREADS)), dim3(CHAIN_THREADS), 0, c.stream, P);
     HIP_CHECK(hipGetLastError());
   }
-  if (P.defer_list) {
-    HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_count, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    const u32 deferred = c.h_scalars[0];
+  if (P.defer_list || all_second) {
+    u32 deferred = lay.n_chains;
+    if (!all_second) {
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_count, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      deferred = c.h_scalars[0];
+    }
     if (deferred > 0) {
       RankIndex ix;
       build_rank_index(c, l, ix);

@@ -1759,7 +1759,8 @@ void ensure_dc_sample(Ctx &c) {
 // from the packed words, and then on the two ranks.  A group that does not fit raises *fail (the caller has checked
 // the largest group beforehand).
 constexpr int DT_THREADS = 512;
-constexpr int DT_TILE = 512;
+constexpr int DT_TILE = 512;       // window ranks whose groups a workgroup owns: groups of up to DT_CAP - DT_TILE + 1 members fit
+constexpr int DT_TILE_WIDE = 768;  // the same where no group has more than DT_CAP - DT_TILE_WIDE + 1 members
 constexpr int DT_CAP = 1024;
 constexpr int DT_EPT = DT_CAP / DT_THREADS;  // entries per thread
 
@@ -1769,7 +1770,7 @@ constexpr int DT_EPT = DT_CAP / DT_THREADS;  // entries per thread
 // that hold the position mod v and the "ends inside its key" flag: a pair then costs one 8-byte look-up for the other
 // member's symbols and flags, one shift and one compare for their common prefix.  Needs nx * xbits <= 58.
 template <class View, int XW, bool PK>
-__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0, u32 nx, u32 xbits, u32 min_sym) {
+__global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView dc, u32 K0, u32 nx, u32 xbits, u32 min_sym, u32 tile) {
   constexpr int XS = PK ? 1 : XW;         // words staged per member
   __shared__ u32 Rw[DT_CAP * DC_ND_MAX];  // first the entries' keys (two words each), then the windows of sample ranks
   __shared__ u64 Xw[XS ? DT_CAP * XS : 1];  // first the head scan's partial results
@@ -1782,7 +1783,7 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
   __shared__ u32 tmx_own[XS ? 1 : DT_THREADS];
   static_assert(DT_CAP == DT_EPT * DT_THREADS && DC_ND_MAX * 4 >= 8 && (!PK || XW > 0), "the keys fit the rank windows");
   const u32 tid = threadIdx.x;
-  const u64 base = (u64)blockIdx.x * DT_TILE;
+  const u64 base = (u64)blockIdx.x * tile;
   const u32 cnt = E.N - base < (u64)DT_CAP ? (u32)(E.N - base) : (u32)DT_CAP;
   u64 *keyb = reinterpret_cast<u64 *>(Rw);
   u32 *tmx = XS ? reinterpret_cast<u32 *>(Xw) : tmx_own;
@@ -1798,7 +1799,7 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
   __syncthreads();
   auto is_head = [&](u32 i) { return (base + i == 0) || keyb[i] != (i ? keyb[i - 1] : prev_key); };
   for (u32 i = tid; i < cnt; i += DT_THREADS)
-    if (is_head(i)) atomicMin(&bounds[i < (u32)DT_TILE ? 0 : 1], i);
+    if (is_head(i)) atomicMin(&bounds[i < tile ? 0 : 1], i);
   __syncthreads();
   const u32 lo = bounds[0];
   if (lo == (u32)DT_CAP) return;  // no group starts here: the stretch belongs to a group of an earlier workgroup
@@ -1956,6 +1957,29 @@ __global__ void __launch_bounds__(DT_THREADS) k_dc_emit(LeafEmit<View> E, DcView
   }
 }
 
+// What the pass above needs to know of the sorted window beforehand, without the list of tied suffixes that the general
+// path builds: out[0] += suffixes that share their key with a neighbour; out[1] = 1 if a group has more than `limit`
+// members (in sorted order that is: some key equals the key `limit` ranks further on), out[2] likewise for `limit2`.
+constexpr int TS_PER_THREAD = 32;  // (one atomic per workgroup on one address: few workgroups)
+template <class View>
+__global__ void __launch_bounds__(256) k_tie_stats(View v, u64 N, u64 mask, u32 limit, u32 limit2, u32 *__restrict__ out) {
+  __shared__ u32 scan_s[17];
+  const u64 first = (u64)blockIdx.x * (256 * TS_PER_THREAD) + threadIdx.x;
+  u32 tied = 0;
+  for (int r = 0; r < TS_PER_THREAD; r++) {
+    const u64 i = first + (u64)r * 256;
+    if (i >= N) break;
+    const u64 k = v.key(i) & mask;
+    const bool t = (i > 0 && (v.key(i - 1) & mask) == k) || (i + 1 < N && (v.key(i + 1) & mask) == k);
+    if (t && i + limit < N && (v.key(i + limit) & mask) == k) out[1] = 1;
+    if (t && i + limit2 < N && (v.key(i + limit2) & mask) == k) out[2] = 1;
+    tied += t;
+  }
+  u32 tot;
+  block_scan_incl<OpSum>(tied, scan_s, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(&out[0], tot);
+}
+
 // Is the pass above the way to finish this window?  M tied suffixes of N, the largest group, K0 symbols in the keys.
 static bool dc_pass_applies(Ctx &c, u64 N, u32 M, u32 max_group, int K0, bool repeats) {
   if (c.dc_mode <= 0 || M == 0) return false;
@@ -2047,12 +2071,25 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
   u32 *wl_pos = scratch + N;
   u32 *wl_grp = grp_buf;
   u32 M, max_group;
-  {
+  if (dc_state == 1 && c.dc_mode > 0) {
+    // the window was sorted for the sample ranks: how many ties there are and whether every group fits is all that
+    // pass needs to know
+    Phase ph(c, "leaf_group", (double)N * 8);
+    u32 *d_stats = c.d_scalars + 26;
+    HIP_CHECK(hipMemsetAsync(d_stats, 0, 3 * sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_tie_stats<View>, dim3(ceil_div(N, 256 * TS_PER_THREAD)), dim3(256), 0, c.stream, v, N, sym_mask,
+                       (u32)(DT_CAP - DT_TILE + 1), (u32)(DT_CAP - DT_TILE_WIDE + 1), d_stats);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 26, d_stats, 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    M = c.h_scalars[26];
+    max_group = c.h_scalars[27] ? (u32)(DT_CAP - DT_TILE + 2) : (c.h_scalars[28] ? (u32)(DT_CAP - DT_TILE_WIDE + 2) : 0u);
+  } else {
     Phase ph(c, "leaf_group", (double)N * (e_w ? 16 : 16));
     u32 *d_maxg = c.d_scalars + 11;
     HIP_CHECK(hipMemsetAsync(d_maxg, 0, sizeof(u32), c.stream));
     scan_generic<TieHead, TieHeadOp>(c, N, ViewTies<View>{v, N, sym_mask},
-                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N, d_maxg, sym_mask, (u32)(DT_CAP - DT_TILE + 1)});
+                                     FirstListOut<View>{v, wl_slot, wl_pos, wl_grp, d_total, N, d_maxg, sym_mask, (u32)(DT_CAP - DT_TILE_WIDE + 1)});
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 8, d_total, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
     HIP_CHECK(hipMemcpyAsync(c.h_scalars + 11, d_maxg, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
     c.sync();
@@ -2091,11 +2128,12 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
       em.n = (u64)c.n;
       HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
       const DcView dv = dc_view(c);
-      const dim3 grid(ceil_div(N, DT_TILE)), block(DT_THREADS);
+      const u32 tile = max_group <= (u32)(DT_CAP - DT_TILE_WIDE + 1) ? DT_TILE_WIDE : DT_TILE;
+      const dim3 grid(ceil_div(N, tile)), block(DT_THREADS);
       const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
       const u32 xbits = (u32)bits_for((u64)(c.max_sym - (int)min_sym + 1));  // codes symbol - min_sym + 1
       const bool pk = nx > 0 && nx * xbits <= 58;
-#define DC_EMIT(XW, PK) hipLaunchKernelGGL((k_dc_emit<View, XW, PK>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym)
+#define DC_EMIT(XW, PK) hipLaunchKernelGGL((k_dc_emit<View, XW, PK>), grid, block, 0, c.stream, em, dv, (u32)K0, nx, xbits, min_sym, tile)
       if (nx == 0) DC_EMIT(0, false);
       else if (nx <= 8) { if (pk) DC_EMIT(1, true); else DC_EMIT(1, false); }
       else if (nx <= 16) { if (pk) DC_EMIT(2, true); else DC_EMIT(2, false); }

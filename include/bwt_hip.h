@@ -178,6 +178,16 @@ int bwt_hip_block_ibwt(bwt_hip_ctx *ctx, bwt_hip_block *blk, uint8_t *I_host, in
 /* Batched bwt::sa (include/bwt.h:456-481): pos_out[k] = text position of the suffix of absolute rank rank[k]. */
 int bwt_hip_block_sa(bwt_hip_ctx *ctx, bwt_hip_block *blk, int64_t nq, const int64_t *rank, int64_t *pos_out);
 
+/* The ranks of a difference-cover sample of the whole text: what README.md:109 of the reference lists as missing there
+   ("a suffix array of sampled characters from the whole input to guarantee a single string comparison does not take too
+   long").  Sample positions are those p with p mod *period in a perfect difference set, so that any two suffixes i, j
+   have a shift d < *period with i + d and j + d both sampled: they compare in at most *period symbols plus two ranks.
+   The library builds the sample by itself when a leaf's ties are dense (texts with long repeats) and then settles the
+   leaf's ties and the chains' suffix comparisons with it; this call builds it if need be and copies it out:
+   pos_out[k] ascending, rank_out[k] = rank of T[pos_out[k]:] among the sampled suffixes, min(*n_out, cap) entries.
+   Any output pointer may be null. */
+int bwt_hip_dc_sample(bwt_hip_ctx *ctx, int64_t cap, int64_t *pos_out, int64_t *rank_out, int64_t *n_out, int *period);
+
 /* build_gap (include/bwt.h:730-787) without consuming the blocks:
    gap_out[i - l.a] = gap.get(i) for i in [l.a, l.b] (l.b-l.a+1 entries);
    g_out[j - r.a] = insertion point of T[j:] among l's suffixes, absolute
