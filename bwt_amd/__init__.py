@@ -68,6 +68,7 @@ def lib():
         "bwt_hip_block_LF": [vp, vp, i64, _u8p, _i64p, _i64p],
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dc_sample": [vp, i64, _i64p, _i64p, _i64p, C.POINTER(i32)],
+        "bwt_hip_leaf_capacity": [vp, i64, _i64p],
         "bwt_hip_block_ibwt": [vp, vp, _u8p, _i64p],
         "bwt_hip_block_sa": [vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dist_bounds": [i64, i32, _i64p],

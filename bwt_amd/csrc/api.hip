@@ -96,6 +96,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_DC")) c.dc_mode = atoi(v);
+  if (const char *v = getenv("BWT_HIP_LEAN_BASE")) c.lean_base = atoi(v) != 0;
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current
   *out = h.release();
   API_END
@@ -315,6 +316,21 @@ int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t th, int64_t ns, int64_t seg, bwt_hip
   // difference-cover sample) is made again if this one needs it
   drop_dc_sample(ctx->c);
   return bwt_hip_rec(ctx, 0, ctx->c.n, th, ns, seg, out);
+}
+
+int bwt_hip_leaf_capacity(bwt_hip_ctx *ctx, int64_t n, int64_t *max_leaf) {
+  API_BEGIN
+  need(ctx && max_leaf && n >= 1, "ctx, max_leaf, n >= 1");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  size_t free_b = 0, total_b = 0;
+  HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  // what the pool already holds from the driver is free to a build as well
+  const double avail = 0.9 * ((double)free_b + (double)c.bytes_reserved - (double)c.bytes_live);
+  // measured peaks: 18.6 bytes per symbol for one leaf of the whole text, 10.3 for two leaves and their merge
+  const double leaf = (avail - 3.0 * (double)n) / 17.0;
+  *max_leaf = avail < 10.5 * (double)n || leaf < 1 ? 0 : (leaf > (double)n ? n : (int64_t)leaf);
+  API_END
 }
 
 // max symbol, smallest non-zero symbol and number of zeros of a host text, on a few host threads

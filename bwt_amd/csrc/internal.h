@@ -116,6 +116,7 @@ struct Ctx {
   int force_wide = 0;
   int wide_bbits = 0;
   bool lean_any_order = true;
+  bool lean_base = true;  // alphabets of 3, 5, 6, 7 symbols: lean keys as numbers in that base (off: such windows are sorted as pairs)
   bool gap_lean = true;  // the gap histogram's grouping in two passes that keep neither digit (gap_sort_lean)
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
   // the left block's suffix array (gap.hip); off: they restart from further and further right instead
@@ -298,6 +299,13 @@ struct TextKeys {
   // tiles that never cross the regions the first pass made (equal d1), so that the bucket of (d2, d1) starts
   // where the second pass's scanned tile counts say.  K0 covers b2 + b1 + lean_deep bits.
   int lean, b1, b2, lean_deep, vbits;
+  // base != 0 (lean elements of alphabets of 3, 5, 6 or 7 symbols): the K0 codes c - min_sym are the digits of a number
+  // in that base instead of bit fields -- 24 symbols of a five-letter alphabet fit 56 bits where 3-bit fields hold 18 --
+  // and key = number * scale in the bits 8..63 (scale = floor(2^56 / base^K0): the keys then reach up to the top of
+  // their 56 bits and the top bits make buckets of even size).  lead = base^(K0-1).  Two keys that agree on their top
+  // bits need not agree on any whole symbol: ties on such keys are compared on the text from the suffixes' first symbol.
+  u32 base;
+  u64 scale, lead;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).

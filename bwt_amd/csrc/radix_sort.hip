@@ -91,7 +91,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
   const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
-  if (w == 2 && !tk.one_based && K0 + ITEMS <= 32) {
+  if (w == 2 && !tk.one_based && !tk.base && K0 + ITEMS <= 32) {
     // Four symbols with 2-bit codes: four symbols per step.  Subtracting min_sym from every byte leaves
     // 0..3 in each; one multiplication gathers the four 2-bit fields, first symbol highest, in bits
     // 24..31 (the partial products land on distinct bits, so nothing carries).  A word with a zero byte
@@ -125,6 +125,23 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   }
   u64 sf = 0;
   u32 wd = 0;
+  if (tk.base) {
+    // the codes as digits of a number: roll = take the leading digit off, shift by one digit, add the new one
+    const u64 B = tk.base;
+    for (int k = 0; k < K0; k++) {
+      if ((k & 3) == 0) wd = src[k >> 2];
+      const u32 ch = wd & 255u;
+      sf = sf * B + (ch ? ch - ms : 0u);
+      wd >>= 8;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      key_out[j] = ((sf * tk.scale) << 8) | raw[j - 1];
+      const u32 out = raw[j], in = raw[K0 + j];
+      sf = (sf - (u64)(out ? out - ms : 0u) * tk.lead) * B + (in ? in - ms : 0u);
+    }
+    return;
+  }
   for (int k = 0; k < K0; k++) {
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
@@ -773,9 +790,11 @@ __global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride
   u64 sf = 0;
   for (int k = 0; k < tk.K0; k++) {
     const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
-    sf = (sf << tk.w) | (ch ? ch - ms : 0u);
+    if (tk.base) sf = sf * tk.base + (ch ? ch - ms : 0u);
+    else sf = (sf << tk.w) | (ch ? ch - ms : 0u);
   }
-  atomicAdd(&per_bucket[(u32)((sf << (64 - tk.K0 * tk.w)) >> (64 - bbits))], 1u);
+  const u64 key = tk.base ? (sf * tk.scale) << 8 : sf << (64 - tk.K0 * tk.w);
+  atomicAdd(&per_bucket[(u32)(key >> (64 - bbits))], 1u);
 }
 
 void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stride, u32 *per_bucket, int bbits) {
@@ -1111,7 +1130,8 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   const int bbits = text.b1 + text.b2;
   if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 10 || text.pbits < 13 + text.b1 || text.pbits > 32 ||
       n >= (1ull << 32) - 8 || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
-      64 - text.b2 - text.lean_deep < text.pbits + text.vbits || text.K0 * text.w < bbits + text.lean_deep || text.K0 * text.w > 56)
+      64 - text.b2 - text.lean_deep < text.pbits + text.vbits ||
+      (text.base ? (bbits + text.lean_deep > 56 || text.K0 > 56) : (text.K0 * text.w < bbits + text.lean_deep || text.K0 * text.w > 56)))
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad lean layout (b1 %d, b2 %d, deep %d, pbits %d, vbits %d, K0 %d, w %d, n %zu)", text.b1,
          text.b2, text.lean_deep, text.pbits, text.vbits, text.K0, text.w, n);
   if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
@@ -1127,7 +1147,8 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
     first.next_shift = 64 - text.b2;
   }
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
-  if (count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
+  // (not with digits of another base: there every symbol of the key can reach the top bits)
+  if (!text.base && count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
   DBuf<u32> counts(c, (size_t)(text.b2 > 9 ? 1024 : 512) * nblk2);
   DBuf<u32> tfirst(c, nd1 + 1);
   DBuf<uint2> tmap(c, nblk2);

@@ -2294,33 +2294,59 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
   if (N < c.bucket_min_n || N < 2 || N >= (1ull << 32) - 8) return 0;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
-  const int one_based = pow2 ? 0 : 1;
+  // Alphabets of 3, 5, 6 or 7 symbols (DNA with N): the codes as digits of a number in that base, scaled to the top of
+  // 56 bits (TextKeys::base) -- bit fields would spend 2 or 3 bits on 1.6 to 2.8 bits of information and leave dozens
+  // of suffixes per key value.
+  const u32 base = (!pow2 && span + 1 >= 3 && span + 1 <= 7 && c.lean_base) ? (u32)(span + 1) : 0u;
+  const int one_based = (pow2 || base) ? 0 : 1;
   const int w = bits_for((u64)(span + one_based));
+  int K0b = 0;
+  u64 lead = 1, scale = 1;
+  double fill = 1.0;  // the part of the key space that keys of a text with all symbols equally frequent reach
+  if (base) {
+    u64 pw = 1;
+    while (pw <= (1ull << 56) / base) {
+      lead = pw;
+      pw *= base;
+      K0b++;
+    }
+    scale = (1ull << 56) / pw;
+    fill = (double)(scale * pw) / (double)(1ull << 56);
+  }
   // buckets of 4100 to 8200 suffixes (the largest bucket of a random text then stays below the 9216 a workgroup holds)
   // (2^19 buckets for windows of 2^31 suffixes and more: a 10-bit second digit)
+  const u64 Nf = (u64)((double)N / fill);
   int bbits = 16;
-  while (bbits < 19 && (N >> bbits) > 8200) bbits++;
+  while (bbits < 19 && (Nf >> bbits) > 8200) bbits++;
   if (c.wide_bbits >= 2 && c.wide_bbits <= 19) bbits = c.wide_bbits;
-  if ((N >> bbits) > 8200) return 0;
+  if ((Nf >> bbits) > 8200) return 0;
   const int b2 = bbits > 18 ? 10 : (bbits > 16 ? 9 : (bbits + 1) / 2), b1 = bbits - b2;
   const int vbits = c.sym_bits;
   int pbits = bits_for(N - 1);
   if (pbits < 13 + b1) pbits = 13 + b1;
   int deep = 64 - b2 - vbits - pbits;
   if (deep > 48 - bbits) deep = 48 - bbits;
-  if (deep > 56 / w * w - bbits) deep = 56 / w * w - bbits;
+  if (!base && deep > 56 / w * w - bbits) deep = 56 / w * w - bbits;
   if (deep < 16) return 0;
-  const int K0 = (bbits + deep + w - 1) / w;  // covers every stored key bit (K0 * w <= 56)
-  const int h16 = (bbits + 16) / w;           // symbols covered by the bits the buckets are ordered on
-  const int h = (bbits + deep) / w;           // whole symbols covered by all the key bits of an element
+  const int K0 = base ? K0b : (bbits + deep + w - 1) / w;  // covers every stored key bit (K0 * w <= 56)
+  const int h16 = (bbits + 16) / w;                        // symbols covered by the bits the buckets are ordered on
+  // whole symbols that two elements with the same key bits are known to share: none with digits of another base
+  const int h = base ? 0 : (bbits + deep) / w;
   const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
-  if (h16 < 1 || expected_ties(sigma, h16, N) > 0.25) return 0;
+  if (base) {
+    if ((double)N / (ldexp(1.0, bbits + 16) * fill) > 0.25) return 0;
+  } else if (h16 < 1 || expected_ties(sigma, h16, N) > 0.25) {
+    return 0;
+  }
   TextKeys tk{c.T, (u64)c.n, (u64)a, w, K0, min_sym, one_based, pbits};
   tk.lean = 1;
   tk.b1 = b1;
   tk.b2 = b2;
   tk.lean_deep = deep;
   tk.vbits = vbits;
+  tk.base = base;
+  tk.scale = scale;
+  tk.lead = lead;
   DBuf<u64> eb0(c, N), eb1(c, N);
   u64 *el[2] = {eb0.get(), eb1.get()};
   BucketState bs;

@@ -445,6 +445,15 @@ namespace bwt {
     }
     /* T goes up in chunks while the first leaf is already being sorted; L comes back with the same call */
     bwt_hip_ctx * c = device_session::get().context(opt.device);
+    if (opt.fit_leaves_to_device) {
+      int64_t cap = 0;
+      bwt_hip_ok(bwt_hip_leaf_capacity(c, n, &cap));
+      if (cap > 0) {
+        idx_t leaf = n; /* bwt_rec halves ranges: the first n / 2^k that fits */
+        while (leaf > cap && leaf > 1) leaf = (leaf + 1) / 2;
+        opt.bwt_rec_threshold = leaf;
+      }
+    }
     if (stat_level >= 1) { bwt_hip_ok(bwt_hip_set_timing(c, 1)); bwt_hip_ok(bwt_hip_reset_timers(c)); }
     bwt_hip_block * h = 0;
     bwt_hip_ok(bwt_hip_pmbwt_host(c, T, n, opt.bwt_rec_threshold, opt.ssa_n_samples, opt.build_gap_segment_sz, L, &h));

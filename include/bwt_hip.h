@@ -94,6 +94,11 @@ int bwt_hip_rec(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t bwt_rec_threshol
 int bwt_hip_pmbwt(bwt_hip_ctx *ctx, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
                   int64_t build_gap_segment_sz, bwt_hip_block **out);
 
+/* The longest leaf this GPU's free memory holds next to a text of n symbols (two 8-byte sort elements per leaf suffix
+   plus the text, L and a merge's buffers): what bwt_opt::fit_leaves_to_device sizes the recursion tree with.  The
+   reference derives its leaf size from mem_budget alone (include/opts.h:278-289). */
+int bwt_hip_leaf_capacity(bwt_hip_ctx *ctx, int64_t n, int64_t *max_leaf);
+
 /* bwt::pmbwt as the reference's caller sees it (include/bwt.h:867-883): T in host memory, L delivered to host
    memory (L_host may be null: the block stays on the device only).  Equivalent to bwt_hip_set_text +
    bwt_hip_pmbwt + bwt_hip_block_get_L, with the upload overlapped: the text goes up in chunks on a stream

@@ -49,6 +49,10 @@ namespace bwt {
     int n_gpus; /* pmbwt: GPUs to spread the build over, devices device .. device+n_gpus-1 (0 or 1: one GPU).  The
                    recursion tree is the one bwt_rec_threshold gives; as many GPUs are used as it has subtrees at
                    their depth (a power of two) */
+    int fit_leaves_to_device; /* 1: pmbwt replaces bwt_rec_threshold by the largest leaf the GPU's free memory holds
+                   (n / 2^k for the smallest k that fits): the fewest merges, which on this hardware is the fastest tree
+                   (one leaf of 3.1e9 symbols builds 5 times faster than mem_budget 4's sixteen).  L does not depend on
+                   the tree; the sample set does.  0: the reference's tree */
 
     bwt_opt() {
       mem_budget = 0;
@@ -60,6 +64,7 @@ namespace bwt {
       assert_level = 0;
       device = 0;
       n_gpus = 0;
+      fit_leaves_to_device = 0;
     }
 
     /* number of partial BWTs alive on the right spine of the recursion */

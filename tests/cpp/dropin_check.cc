@@ -112,6 +112,30 @@ int main() {
     printf("OK sa_range, bwt_rec, sampled sa\n");
     delete[] T; delete[] L; delete[] I; delete[] SA;
   }
+  {  // the opt-in tree: leaves as long as the device's memory holds (here the whole text: no merge), same L
+    bwt::idx_t n = 400000;
+    bwt::alpha_t * T = gen(n, 5, 4), * L = new bwt::alpha_t[n], * L2 = new bwt::alpha_t[n];
+    bwt::bwt_opt opt;
+    opt.alpha_min = 1;
+    opt.alpha_max = 4;
+    opt.set_defaults(T, n);
+    bwt::mallocator mem(n, opt);
+    bwt::bwt t = bwt::pmbwt(T, n, L, 0, mem, opt);
+    bwt::bwt_opt opt2;
+    opt2.alpha_min = 1;
+    opt2.alpha_max = 4;
+    opt2.fit_leaves_to_device = 1;
+    opt2.set_defaults(T, n);
+    bwt::mallocator mem2(n, opt2);
+    bwt::bwt t2 = bwt::pmbwt(T, n, L2, 0, mem2, opt2);
+    if (opt2.bwt_rec_threshold != n || opt.bwt_rec_threshold >= n) return fail("fit_leaves_to_device sizes the leaf");
+    if (memcmp(L, L2, n) != 0 || t.s_rank != t2.s_rank) return fail("fit_leaves_to_device: same L");
+    if (t2.round_trip_mismatches() != 0) return fail("fit_leaves_to_device: round trip");
+    t.fini(mem, opt);
+    t2.fini(mem2, opt2);
+    printf("OK fit_leaves_to_device\n");
+    delete[] T; delete[] L; delete[] L2;
+  }
   {  // build_gap and resample_sa called by hand (reference include/bwt.h:730-787, :366-453) against a direct count
      // and against the samples the device merge keeps
     bwt::idx_t n = 9000, a = 300, b = 8700, c = (a + b) / 2;

@@ -9,7 +9,12 @@ reference computed for them -- never reference source.
     python tests/golden/make_golden.py        # rewrites golden.json
 
 Hashes are FNV-1a-64 over the raw bytes (uint8 arrays) or over the
-little-endian int64 image (index arrays).
+little-endian int64 image (index arrays): offset basis 0xcbf29ce484222325,
+prime 0x100000001b3, one byte per step (tests/golden_util.py).  For the
+splitmix64 seed-42 DNA text of 1e6 symbols that gives L = a5b14c6aea1f33b4 with
+s_rank 471118.  Hash values quoted elsewhere for the same texts with the same
+s_rank but other digits (901bd18da962c3e6 for this one) came from a throw-away
+harness with a different hash function, not from a different L.
 """
 import json
 import os

@@ -42,11 +42,17 @@ def main():
     same_as_oracle(ctx, T, ord("d"), 50000, 700, 200)
     assert lean_launches(ctx) == before + 4
     # alphabets that are not a power of two (one-based codes), 2 to 8 bits per symbol
-    for sigma in (2, 3, 5, 7, 8, 15, 16, 26, 100, 255):
+    # (3, 5, 6 and 7 symbols: the keys are numbers in that base, ties compared on the text from the first symbol)
+    for sigma in (2, 3, 5, 6, 7, 8, 15, 16, 26, 100, 255):
         T = gen_text(150000, 20 + sigma, sigma)
         before = lean_launches(ctx)
         same_as_oracle(ctx, T, sigma, 60000, 800)
         assert lean_launches(ctx) == before + 4, sigma
+    # five symbols, the text ending in a run of the smallest one (keys that run into the terminator), and one symbol rare
+    T = gen_text(200000, 9, 5)
+    T[-2000:-1] = 1
+    T[:-1][T[:-1] == 5] = np.where(rng.random(int((T[:-1] == 5).sum())) < 0.02, 5, 2).astype(np.uint8)
+    same_as_oracle(ctx, T, 5, 70000, 500)
     # leaf suffix arrays in the middle of the text
     T = gen_text(250000, 11, 4)
     ctx.set_text(T)

@@ -202,6 +202,13 @@ def test_config5_bytes_n1e9_two_leaves(ctx):
     ctx.trim()
 
 
+def test_five_symbols_n1e9_two_leaves(ctx):
+    """DNA with N as far as the alphabet goes (five equally frequent symbols) at n = 1e9: both leaves on the lean route
+    with keys that are numbers in base 5, against the same tree sorted as (key, position) pairs."""
+    _full_size(ctx, 10 ** 9, 2, 12500000, ["leaf:bucket_emit_items=5,lean"], 4, sigma=5)
+    ctx.trim()
+
+
 def _forced_wide_context():
     """A second context on the same GPU whose large windows take the wide route (8 + 1 byte elements)."""
     import bwt_amd

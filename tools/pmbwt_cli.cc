@@ -52,6 +52,7 @@ static const flag opt_flags[] = {
   { "assert_level", 0, 'n', offsetof(bwt::bwt_opt, assert_level) },
   { "device", 0, 'n', offsetof(bwt::bwt_opt, device) },
   { "n_gpus", 0, 'n', offsetof(bwt::bwt_opt, n_gpus) },
+  { "fit_leaves_to_device", 0, 'n', offsetof(bwt::bwt_opt, fit_leaves_to_device) },
 };
 static const char * cli_flags[] = { "n_workers", "alpha_min", "alpha_max", "stat_level", "mstat_level", "check",
                                     "repeat", "ssa_n_samples", "bwt_rec_threshold", "seed", "generator", "input",
