@@ -14,5 +14,5 @@ cp $OUT/phase_times.txt $R/gpurun_out/r3_${TAG}_phase_times.txt
 if [ "$PMC" = "pmc" ]; then
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/tools/phase_times.py "$@" > $OUT/fetch.log 2>&1 || exit 2
   timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/tools/phase_times.py "$@" > $OUT/write.log 2>&1 || exit 3
-  { echo "rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes) of: tools/phase_times.py $*"; echo "per dispatch averages as the counters report them (units of 1 byte after rocprofv3's own scaling; streaming reads count half their bytes on gfx950, random sectors whole):"; python3 $R/tools/pmc_summary.py $OUT/fetch/f_counter_collection.csv; python3 $R/tools/pmc_summary.py $OUT/write/w_counter_collection.csv; } > $R/gpurun_out/r3_${TAG}_pmc_traffic.txt
+  { echo "rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes) of: tools/phase_times.py $*"; echo "per dispatch averages as the counters report them (in KB; a 128-byte read request is tallied as 64 bytes on gfx950):"; python3 $R/tools/pmc_summary.py $OUT/fetch/f_counter_collection.csv; python3 $R/tools/pmc_summary.py $OUT/write/w_counter_collection.csv; } > $R/gpurun_out/r3_${TAG}_pmc_traffic.txt
 fi
