@@ -423,10 +423,70 @@ static std::unique_ptr<DistBlock> dist_merge(Group &g, std::unique_ptr<DistBlock
   return out;
 }
 
+// out[y] = the filled one of in[0][y] .. in[sources-1][y] (~0 = empty: the minimum)
+__global__ void k_merge_slots(const u64 *__restrict__ in, u64 n, u32 sources, u64 *__restrict__ out) {
+  const u64 y = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= n) return;
+  u64 v = ~0ull;
+  for (u32 s = 0; s < sources; s++) {
+    const u64 x = in[(u64)s * n + y];
+    v = x < v ? x : v;
+  }
+  out[y] = v;
+}
+
+// The whole text as ONE leaf over all ranks (a tree without merges: bwt_rec_threshold >= n).  The reference sorts a
+// leaf in one address space (include/bwt.h:615-635, include/suffix_array.h:34-49); here every rank holds the text,
+// builds the stretch of the leaf's suffix order whose keys begin with its share of first digits (build_leaf_share:
+// the shares are cut the same way by every rank, from its own count of the whole text) and ends up with slice `rank`
+// of L.  What is exchanged: the special ranks (two numbers per rank) and the sample slots -- a rank's share holds
+// suffixes from all over the text, so every rank sends each other rank the slots of that rank's position range and
+// keeps the filled ones of what it receives.
+static std::unique_ptr<DistBlock> dist_leaf(Ctx &c, bwt_hip_transport *t, i64 ns_req) {
+  const int world = t->world, me = t->rank;
+  const i64 n = c.n;
+  LeafShare sh;
+  if (!build_leaf_share(c, 0, n, ns_req, me, world, sh))
+    fail(BWT_HIP_ENOROUTE, "a leaf over %d GPUs needs a text that takes the lean bucket route (1e8 symbols and more, no long repeats): build this one as a tree of at least %d leaves", world, world);
+  Group g{t, c, 0, world, me, me};
+  std::unique_ptr<DistBlock> out(new DistBlock());
+  out->a = 0;
+  out->b = n;
+  out->first = 0;
+  out->q = world;
+  for (int j = 0; j < world; j++) out->sizes.push_back((i64)(sh.bounds[(size_t)j + 1] - sh.bounds[(size_t)j]));
+  out->L = std::move(sh.L);
+  std::vector<i64> sp = g.all_gather({sh.s_rank, sh.e_rank});
+  for (int j = 0; j < world; j++) {
+    if (sp[(size_t)j * 2] >= 0) out->s_rank = sp[(size_t)j * 2];
+    if (sp[(size_t)j * 2 + 1] >= 0) out->e_rank = sp[(size_t)j * 2 + 1];
+  }
+  if (out->s_rank < 0 || out->e_rank < 0) fail(BWT_HIP_EINTERNAL, "leaf over %d GPUs: no share holds the first or the last suffix", world);
+  // sample slots: rank j gets the slots [ns * j / world, ns * (j + 1) / world) of every share
+  const i64 ns = sh.ns;
+  auto cut = [&](int j) { return ns * (i64)j / (i64)world; };
+  const i64 my_lo = cut(me), my_cnt = cut(me + 1) - my_lo;
+  DBuf<u64> in(c, (size_t)(my_cnt > 0 ? my_cnt : 1) * (size_t)world);
+  std::vector<i64> send_b((size_t)world), recv_b((size_t)world, my_cnt * 8);
+  for (int j = 0; j < world; j++) send_b[(size_t)j] = (cut(j + 1) - cut(j)) * 8;
+  g.all_to_all((const u8 *)sh.samp.get(), send_b, (u8 *)in.get(), recv_b);
+  DBuf<u64> merged(c, (size_t)(my_cnt > 0 ? my_cnt : 1));
+  launch1d(c, k_merge_slots, (u64)my_cnt, (const u64 *)in.get(), (u64)my_cnt, (u32)world, merged.get());
+  out->samp_rank = DBuf<u32>(c, (size_t)(my_cnt > 0 ? my_cnt : 1));
+  out->samp_pos = DBuf<u32>(c, (size_t)(my_cnt > 0 ? my_cnt : 1));
+  out->n_samp = compact_sample_slots(c, merged.get(), my_cnt, 0u, out->samp_rank.get(), out->samp_pos.get());
+  c.sync();
+  return out;
+}
+
 static std::unique_ptr<DistBlock> dist_build(Ctx &c, bwt_hip_transport *t, i64 th, i64 ns, i64 seg) {
   const int world = t->world, me = t->rank;
   if (world < 1 || (world & (world - 1)) || me < 0 || me >= world) fail(BWT_HIP_EINVAL, "rank %d of %d: the number of ranks must be a power of two", me, world);
   if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
+  if (world > 1 && (th >= c.n || c.n < 2)) {  // the tree is one leaf: the ranks share it by key range
+    drop_dc_sample(c);
+    return dist_leaf(c, t, ns);
+  }
   int depth = 0;
   while ((1 << depth) < world) depth++;
   if (!tree_reaches(c.n, th, depth))
@@ -785,20 +845,24 @@ int bwt_hip_slice_get_samples(bwt_hip_ctx *ctx, const bwt_hip_slice *s_, int64_t
 
 void bwt_hip_slice_free(bwt_hip_slice *s) { delete reinterpret_cast<Slice *>(s); }
 
-int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns,
-                        int64_t seg, uint8_t *L_host, int64_t *s_rank, int64_t *e_rank, int64_t *samp_rank,
-                        int64_t *samp_pos, int64_t samp_cap, int64_t *n_samples, int *used) {
-  DIST_BEGIN
+static void pmbwt_multi_impl(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns,
+                             int64_t seg, uint8_t *L_host, int64_t *s_rank, int64_t *e_rank, int64_t *samp_rank,
+                             int64_t *samp_pos, int64_t samp_cap, int64_t *n_samples, int *used, bool one_device_only) {
+  {
   if (!devices || n_devices < 1 || !T_host || !L_host || n < 1 || th < 1) fail(BWT_HIP_EINVAL, "invalid argument: devices, T_host, L_host, n >= 1, bwt_rec_threshold >= 1");
   int world = 1, depth = 0;
   while (world * 2 <= n_devices && tree_reaches(n, th, depth + 1)) {
     world *= 2;
     depth++;
   }
+  // a tree of one leaf: the GPUs share the leaf by key range (dist_leaf), where the text takes the route that needs
+  const bool one_leaf = world == 1 && n_devices >= 2 && th >= n && !one_device_only;
+  if (one_leaf)
+    while (world * 2 <= n_devices) world *= 2;
   if (used) *used = world;
   std::vector<bwt_hip_transport *> tr((size_t)world, nullptr);
   int rc0 = bwt_hip_transport_local(world, tr.data());
-  if (rc0 != 0) return rc0;
+  if (rc0 != 0) fail(rc0, "%s", bwt_hip_last_error());
   std::vector<int> rcs((size_t)world, 0);
   std::vector<std::string> msgs((size_t)world);
   std::vector<bwt_hip_ctx *> ctxs((size_t)world, nullptr);
@@ -855,5 +919,19 @@ int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host
   }
   for (int k = 0; k < world; k++)
     if (rcs[(size_t)k] != 0) fail(rcs[(size_t)k], "rank %d: %s", k, msgs[(size_t)k].c_str());
+  }
+}
+
+int bwt_hip_pmbwt_multi(const int *devices, int n_devices, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns,
+                        int64_t seg, uint8_t *L_host, int64_t *s_rank, int64_t *e_rank, int64_t *samp_rank,
+                        int64_t *samp_pos, int64_t samp_cap, int64_t *n_samples, int *used) {
+  DIST_BEGIN
+  try {
+    pmbwt_multi_impl(devices, n_devices, T_host, n, th, ns, seg, L_host, s_rank, e_rank, samp_rank, samp_pos, samp_cap, n_samples, used, false);
+  } catch (const Error &e) {
+    if (e.code != BWT_HIP_ENOROUTE) throw;
+    // a tree of one leaf whose text does not take the route that GPUs can share: one GPU builds it
+    pmbwt_multi_impl(devices, n_devices, T_host, n, th, ns, seg, L_host, s_rank, e_rank, samp_rank, samp_pos, samp_cap, n_samples, used, true);
+  }
   DIST_END
 }

@@ -47,6 +47,7 @@ struct Error : std::runtime_error {
 #define BWT_HIP_ETEXT 10002
 #define BWT_HIP_EINTERNAL 10003
 #endif
+#define BWT_HIP_ENOROUTE 10004  // internal: a build that needs a particular route was asked of a text that does not take it
 
 // ---------------------------------------------------------------------------
 // device context: one per (process, GPU).  All work runs on `stream`.
@@ -293,11 +294,13 @@ struct TextKeys {
   int wide;
   // LEAN elements (lean != 0), for windows below 2^31 suffixes of small symbols: 8 bytes and nothing on the side,
   // because a radix pass need not keep the digit it sorts on -- after the pass that digit is known from where an
-  // element lies.  With the key's top bits cut into | d2, b2 bits | d1, b1 bits | deep, lean_deep bits |:
+  // element lies.  With the key's top bits cut into | d1, b1 bits | d2, b2 bits | deep, lean_deep bits |:
   //   element  | d2 | deep | zero padding | T[a+i-1], vbits | i, pbits |
-  // The text pass sorts on d1 (bits 64-b2-b1 .. 64-b2 of the key) without storing it, the second pass on d2 over
-  // tiles that never cross the regions the first pass made (equal d1), so that the bucket of (d2, d1) starts
-  // where the second pass's scanned tile counts say.  K0 covers b2 + b1 + lean_deep bits.
+  // The text pass sorts on d1 (the key's top b1 bits) without storing it, the second pass on d2 over tiles that never
+  // cross the regions the first pass made (equal d1) and writes region by region, so that the result is in the order
+  // of (d1, d2) and the bucket of (d1, d2) starts where the second pass's tile counts, scanned per region, say.  The
+  // top digit first: a GPU that keeps only a stretch of d1 values (LeanShard) ends up with a stretch of the leaf's
+  // ranks.  K0 covers b1 + b2 + lean_deep bits.
   int lean, b1, b2, lean_deep, vbits;
   // base != 0 (lean elements of alphabets of 3, 5, 6 or 7 symbols): the K0 codes c - min_sym are the digits of a number
   // in that base instead of bit fields -- 24 symbols of a five-letter alphabet fit 56 bits where 3-bit fields hold 18 --
@@ -306,6 +309,9 @@ struct TextKeys {
   // bits need not agree on any whole symbol: ties on such keys are compared on the text from the suffixes' first symbol.
   u32 base;
   u64 scale, lead;
+  // keep_hi != 0 (lean text pass of a leaf that is spread over several GPUs): only the elements whose first digit lies
+  // in [keep_lo, keep_hi) are written
+  u32 keep_lo, keep_hi;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
@@ -330,8 +336,18 @@ void bucket_histogram(Ctx &c, const TextKeys &tk, u64 first, u64 count, u64 stri
 int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits, u32 cap, const TextKeys &text,
                         BucketState *bs);
 // Round 0 with lean elements: two passes, then bs->start holds the bounds of the 2^(b1+b2) buckets (bucket
-// index = d2 << b1 | d1).  Returns the buffer with the result, or -1 if a bucket holds more than cap elements.
-int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs);
+// index = d1 << b2 | d2: the key's top b1 + b2 bits).  Returns the buffer with the result, or -1 if a bucket holds more than cap elements.
+// shard (may be null): in: this GPU's part of `parts` (1: everything); out: the first digits it keeps, the leaf rank of
+// its first suffix and how many it holds.  With parts > 1 the element buffers hold only this GPU's suffixes and
+// bs->start[k] is the leaf rank of bucket k's first suffix (local index + first_rank).  elems: allocated here.
+struct LeanShard {
+  int part = 0, parts = 1;
+  u32 dig_lo = 0, dig_hi = 0;
+  u64 first_rank = 0, count = 0;
+  std::vector<u64> bounds;  // out: leaf rank of every part's first suffix, parts + 1 entries (the same on every GPU)
+  DBuf<u8> L;               // out (leaf builds that ask for L): this part's stretch of L, `count` symbols
+};
+int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard = nullptr);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 // The gap histogram's grouping: the values of keys[0] grouped by their bits [low, low + b1 + b2), in two passes
 // that keep neither digit; afterwards keys[0] holds the values' low `low` bits as 16-bit words, bucket k of them
@@ -389,6 +405,22 @@ void drop_dc_sample(Ctx &c);
 DBuf<u32> leaf_suffix_array(Ctx &c, i64 a, i64 b);
 // suffix_sort.hip: bwt_leaf -- the leaf's L, special ranks and samples
 Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns);
+// suffix_sort.hip: one GPU's share of a leaf that `parts` GPUs build together, cut by key range: every GPU reads the
+// whole text, keeps the suffixes whose key's first digit falls into its stretch (stretches of about equal counts, cut
+// the same way by every GPU from its own histogram: nothing is exchanged) and finishes them, which gives it the stretch
+// [bounds[part], bounds[part+1]) of the leaf's L.  samp: the leaf's ns position-ordered sample slots (position << 32 |
+// leaf rank), filled where the sampled suffix belongs to this share, ~0 elsewhere.  s_rank / e_rank: leaf-relative,
+// -1 where the suffix is another share's.  False: the text or the leaf does not take the route this needs (the lean
+// bucket route: large leaves without long repeats); nothing was built.
+struct LeafShare {
+  DBuf<u8> L;
+  DBuf<u64> samp;
+  std::vector<u64> bounds;
+  i64 ns = 0, s_rank = -1, e_rank = -1;
+};
+bool build_leaf_share(Ctx &c, i64 a, i64 b, i64 ns, int part, int parts, LeafShare &out);
+// the filled slots of a sample slot array, in order, as (rank + rank_base, position) pairs; returns their number
+i64 compact_sample_slots(Ctx &c, const u64 *slots, i64 n_slots, u32 rank_base, u32 *rank_out, u32 *pos_out);
 // wavelet.hip
 void count_alphabets(Ctx &c, Block &blk);
 void build_wavelet(Ctx &c, Block &blk);

@@ -280,7 +280,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
                                                 u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
-                                                u32 lean_tile0 = 0, u32 narrow_mask = 0) {
+                                                u32 lean_tile0 = 0, u32 narrow_mask = 0, u32 keep_lo = 0, u32 keep_hi = 0) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -383,7 +383,12 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     const u32 p = r * RS_THREADS + tid;
     if (FULL || p < tile_n) {
       K k = keys_s[p];
-      u32 dst = gbase[digit_of<K>(k, shift, mask)] + p;
+      const u32 dg = digit_of<K>(k, shift, mask);
+      if constexpr (REVERSE && sizeof(K) == 8 && !HAS_VALS && !SIDE) {
+        // a text pass that keeps only the digits keep_lo .. keep_hi-1 (the caller has zeroed the counts of the others)
+        if (keep_hi && (dg < keep_lo || dg >= keep_hi)) continue;
+      }
+      u32 dst = gbase[dg] + p;
       if constexpr (SPLIT) {
         u32 *klo = reinterpret_cast<u32 *>(kout);
         klo[dst] = (u32)k;
@@ -493,9 +498,9 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
         sd[r] = (u8)((((u32)k >> 28) << 4) | ((u32)k & 0xFu));
       } else if (tk.lean) {
         // lean element as it is staged: | d2 | deep | preceding symbol | d1 above bit 13 | index in the tile |
-        const u64 top = ~0ull << (64 - tk.b2);
-        const u64 hi = ((k & top) | ((k << tk.b1) & ~top)) & (~0ull << (64 - tk.b2 - tk.lean_deep));
-        const u32 d1 = (u32)(k >> (64 - tk.b2 - tk.b1)) & ((1u << tk.b1) - 1u);
+        // (d1 = the key's top b1 bits, which this pass sorts on and does not store; d2 = the b2 bits below them)
+        const u64 hi = (k << tk.b1) & (~0ull << (64 - tk.b2 - tk.lean_deep));
+        const u32 d1 = (u32)(k >> (64 - tk.b1));
         key[r] = (K)(hi | ((u64)((u32)k & 0xFFu) << tk.pbits) | (u64)(d1 << 13) | idx);
       } else {  // packed element: codes | preceding symbol | window index
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
@@ -550,11 +555,11 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                              lean_posmask, (u32)tile0, narrow_mask);
+                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                               lean_posmask, (u32)tile0, narrow_mask);
+                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -971,7 +976,8 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
 // regions below d (nd1 + 1 entries), tmap[t] = (first element, elements) of tile t; the tiles from tfirst[nd1] on
 // are empty (the caller's nblk2 is an upper bound that leaves at least one of them).
 __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ offs1, u32 nblk, u32 nd1, u32 n,
-                                                     u32 *__restrict__ tfirst, uint2 *__restrict__ tmap, u32 nblk2) {
+                                                     u32 *__restrict__ tfirst, uint2 *__restrict__ tmap, u32 nblk2,
+                                                     u32 *__restrict__ rstart = nullptr) {
   __shared__ u32 rs[513], tf[513];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
@@ -985,6 +991,7 @@ __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ off
   if (tid == nd1) tf[tid] = total;
   __syncthreads();
   if (tid <= nd1) tfirst[tid] = tf[tid];
+  if (rstart && tid <= nd1) rstart[tid] = rs[tid];  // first element of every region
   for (u32 t = tid; t < nblk2; t += 1024) {
     if (t >= total) {
       tmap[t] = make_uint2(n, 0u);
@@ -1011,19 +1018,86 @@ __global__ void k_lean_bucket_starts(const u32 *__restrict__ offs2, u32 nblk2, c
   start[k] = k == n_buckets ? n : offs2[(size_t)(k >> b1) * nblk2 + tfirst[k & ((1u << b1) - 1u)]];
 }
 
+// The leaf sort's second pass writes REGION by region (the first pass sorted on the key's top digit, so the final order
+// is region, then second digit): the offsets of its tile counts, [digit][tile], are therefore scanned per region -- all
+// tiles of the region's digit 0, then digit 1, ... -- from the region's first element on, in place.  One workgroup per
+// region; every wave sums, then scans, the digits it owns, so that no barrier separates the digits.
+constexpr int LR_THREADS = 512;
+__global__ void __launch_bounds__(LR_THREADS) k_lean_region_scan(u32 *__restrict__ counts, u32 nblk2, const u32 *__restrict__ tfirst,
+                                                                 const u32 *__restrict__ rstart, u32 ndig) {
+  __shared__ u32 tot_s[1024];
+  __shared__ u32 scan_s[17];
+  const u32 r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = LR_THREADS / 64;
+  const u32 t0 = tfirst[r], t1 = tfirst[r + 1];
+  if (t0 == t1) return;
+  for (u32 d = w; d < ndig; d += nw) {
+    u32 sum = 0;
+    for (u32 t = t0 + lane; t < t1; t += 64) sum += counts[(size_t)d * nblk2 + t];
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) tot_s[d] = sum;
+  }
+  __syncthreads();
+  // exclusive prefix sums of the digits' totals (ndig <= 1024 = two values per thread)
+  const u32 a = 2 * tid < ndig ? tot_s[2 * tid] : 0u, b = 2 * tid + 1 < ndig ? tot_s[2 * tid + 1] : 0u;
+  u32 all;
+  const u32 incl = block_scan_incl<OpSum>(a + b, scan_s, &all);
+  __syncthreads();
+  if (2 * tid < ndig) tot_s[2 * tid] = rstart[r] + incl - a - b;
+  if (2 * tid + 1 < ndig) tot_s[2 * tid + 1] = rstart[r] + incl - b;
+  __syncthreads();
+  for (u32 d = w; d < ndig; d += nw) {
+    u32 run = tot_s[d];
+    for (u32 tb = t0; tb < t1; tb += 64) {
+      const u32 t = tb + lane;
+      const u32 v = t < t1 ? counts[(size_t)d * nblk2 + t] : 0u;
+      const u32 in = wave_scan_incl_sum(v);
+      if (t < t1) counts[(size_t)d * nblk2 + t] = run + in - v;
+      run += __shfl(in, 63, 64);
+    }
+  }
+}
+
+// start[d1 << b2 | d2] = first element of that bucket after the second pass of the leaf sort, plus `base`: the scanned
+// count of digit d2 at the first tile of region d1; an empty region's buckets all begin where the region does.
+// start[n_buckets] = base + n.
+__global__ void k_lean_bucket_starts_msd(const u32 *__restrict__ offs2, u32 nblk2, const u32 *__restrict__ tfirst,
+                                         const u32 *__restrict__ rstart, int b2, u32 n_buckets, u32 n, u32 base, u32 *__restrict__ start) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_buckets) return;
+  if (k == n_buckets) {
+    start[k] = base + n;
+    return;
+  }
+  const u32 r = k >> b2, d = k & ((1u << b2) - 1u);
+  start[k] = base + (tfirst[r] == tfirst[r + 1] ? rstart[r] : offs2[(size_t)d * nblk2 + tfirst[r]]);
+}
+
 // Neither pass needs a stable order: a bucket is ordered in LDS afterwards, and when that gives up nothing of this
 // sort is used.  So both rank their tiles with one LDS atomic per element (ANY_ORDER).
+// per_digit[d] = sum over the tiles of counts[d][.] (one wave per digit)
+__global__ void __launch_bounds__(256) k_row_sums(const u32 *__restrict__ counts, u32 nblk, u32 ndig, u32 *__restrict__ per_digit) {
+  const u32 d = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (d >= ndig) return;
+  u32 sum = 0;
+  for (u32 t = lane; t < nblk; t += 64) sum += counts[(size_t)d * nblk + t];
+  sum = wave_reduce_sum(sum);
+  if (lane == 0) per_digit[d] = sum;
+}
+
+// The text pass in two steps, so that a caller can look at the digits' totals in between (LeanShard).
 template <int DB>
-static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, const TextKeys &count_keys, u32 *counts) {
-  const int shift = 64 - tk.b2 - tk.b1;
+static void lean_text_hist(Ctx &c, size_t n, u32 nblk, const TextKeys &tk, const TextKeys &count_keys, u32 *counts) {
+  const int shift = 64 - tk.b1;
   const u32 mask = (1u << tk.b1) - 1u;
-  {
-    KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
-    hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
-                       mask, counts, nblk, count_keys, (const uint2 *)nullptr);
-    HIP_CHECK(hipGetLastError());
-  }
-  scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk, nullptr);
+  KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
+  hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
+                     mask, counts, nblk, count_keys, (const uint2 *)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int DB>
+static void lean_text_scatter(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, u32 *counts) {
+  const u32 mask = (1u << tk.b1) - 1u;
   KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
   // the staged elements carry the digit above the low 13 bits of their position field
   if (c.lean_any_order)
@@ -1039,7 +1113,7 @@ static void lean_text_pass(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys 
 
 template <int DB>
 static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk2, const TextKeys &tk, u32 *counts,
-                             const uint2 *tmap, const u8 *digits) {
+                             const uint2 *tmap, const u8 *digits, const u32 *tfirst, const u32 *rstart) {
   TextKeys none;
   memset(&none, 0, sizeof(none));
   const int shift = 64 - tk.b2;
@@ -1054,7 +1128,11 @@ static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk
                        nblk2, none, tmap);
     HIP_CHECK(hipGetLastError());
   }
-  scan_exclusive_u32(c, counts, counts, (size_t)(1 << DB) * nblk2, nullptr);
+  {
+    KernelTimer kt(c, "leaf:k_lean_region_scan", (double)(1 << DB) * nblk2 * 12);
+    hipLaunchKernelGGL(k_lean_region_scan, dim3(1u << tk.b1), dim3(LR_THREADS), 0, c.stream, counts, nblk2, tfirst, rstart, (u32)(1 << DB));
+    HIP_CHECK(hipGetLastError());
+  }
   KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
   if (c.lean_any_order)
     hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, true, false, DB>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream, in,
@@ -1126,7 +1204,7 @@ void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 
   else gap_sort_lean_impl<8, 8>(c, keys, n, low, b1, b2, start);
 }
 
-int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs) {
+int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard) {
   const int bbits = text.b1 + text.b2;
   if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 10 || text.pbits < 13 + text.b1 || text.pbits > 32 ||
       n >= (1ull << 32) - 8 || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
@@ -1140,33 +1218,78 @@ int leaf_sort_text_lean(Ctx &c, u64 *elems[2], size_t n, u32 cap, const TextKeys
   const u32 nblk2 = nblk + nd1 + 1;
   TextKeys first = text;
   first.next_digits = nullptr;
-  DBuf<u8> digits;
-  if (text.b2 <= 8) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
-    digits = DBuf<u8>(c, n + 16);
-    first.next_digits = digits.get();
-    first.next_shift = 64 - text.b2;
-  }
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
   // (not with digits of another base: there every symbol of the key can reach the top bits)
   if (!text.base && count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
   DBuf<u32> counts(c, (size_t)(text.b2 > 9 ? 1024 : 512) * nblk2);
-  DBuf<u32> tfirst(c, nd1 + 1);
+  DBuf<u32> tfirst(c, nd1 + 1), rstart(c, nd1 + 1);
   DBuf<uint2> tmap(c, nblk2);
-  if (text.b1 > 8) lean_text_pass<9>(c, elems[1], n, nblk, first, count_keys, counts.get());
-  else lean_text_pass<8>(c, elems[1], n, nblk, first, count_keys, counts.get());
-  hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)n, tfirst.get(),
-                     tmap.get(), nblk2);
+  if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
+  else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
+  const u32 dig1 = text.b1 > 8 ? 512u : 256u;  // counter rows of the text pass
+  size_t kept = n;
+  u64 first_rank = 0;
+  if (shard && shard->parts > 1) {
+    // This GPU keeps a stretch of the first digit's values: the `part`-th of `parts` stretches that hold about the
+    // same number of suffixes each.  Every GPU counts the whole text and cuts the same way; nothing is exchanged.
+    DBuf<u32> per(c, dig1);
+    hipLaunchKernelGGL(k_row_sums, dim3(ceil_div(dig1, 4)), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk, dig1, per.get());
+    HIP_CHECK(hipGetLastError());
+    std::vector<u32> h(dig1);
+    HIP_CHECK(hipMemcpyAsync(h.data(), per.get(), dig1 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    std::vector<u64> cum(dig1 + 1, 0);
+    for (u32 d = 0; d < dig1; d++) cum[d + 1] = cum[d] + h[d];
+    auto cut = [&](int j) {  // first digit of part j: the first one at which j / parts of the suffixes lie below
+      if (j <= 0) return 0u;
+      if (j >= shard->parts) return nd1;
+      const u64 want = (u64)n * (u64)j / (u64)shard->parts;
+      u32 d = 0;
+      while (d < nd1 && cum[d] < want) d++;
+      return d;
+    };
+    shard->bounds.assign((size_t)shard->parts + 1, 0);
+    for (int j = 0; j <= shard->parts; j++) shard->bounds[(size_t)j] = cum[cut(j)];
+    const u32 lo = cut(shard->part), hi = cut(shard->part + 1);
+    shard->dig_lo = lo;
+    shard->dig_hi = hi;
+    first_rank = cum[lo];
+    kept = (size_t)(cum[hi] - cum[lo]);
+    shard->first_rank = first_rank;
+    shard->count = kept;
+    first.keep_lo = lo;
+    first.keep_hi = hi > lo ? hi : lo + 1;  // (an empty share keeps one digit that holds nothing)
+    if (lo > 0) HIP_CHECK(hipMemsetAsync(counts.get(), 0, (size_t)lo * nblk * sizeof(u32), c.stream));
+    if (hi < dig1) HIP_CHECK(hipMemsetAsync(counts.get() + (size_t)hi * nblk, 0, (size_t)(dig1 - hi) * nblk * sizeof(u32), c.stream));
+  } else if (shard) {
+    shard->first_rank = 0;
+    shard->count = n;
+  }
+  scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, nullptr);
+  const size_t room = kept > 0 ? kept : 1;
+  elems[0] = DBuf<u64>(c, room);
+  elems[1] = DBuf<u64>(c, room);
+  DBuf<u8> digits;
+  if (text.b2 <= 8) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
+    digits = DBuf<u8>(c, room + 16);
+    first.next_digits = digits.get();
+    first.next_shift = 64 - text.b2;
+  }
+  if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, counts.get());
+  else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, counts.get());
+  hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
+                     tmap.get(), nblk2, rstart.get());
   HIP_CHECK(hipGetLastError());
-  if (text.b2 > 9) lean_second_pass<10>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
-  else if (text.b2 > 8) lean_second_pass<9>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), nullptr);
-  else lean_second_pass<8>(c, elems[1], elems[0], n, nblk2, text, counts.get(), tmap.get(), digits.get());
+  if (text.b2 > 9) lean_second_pass<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
+  else if (text.b2 > 8) lean_second_pass<9>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
+  else lean_second_pass<8>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), digits.get(), tfirst.get(), rstart.get());
   bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
   u32 *d_max = c.d_scalars + 12;
   {
     KernelTimer kt(c, "leaf:k_bucket_bounds", (double)n_buckets * 12);
     HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
-    hipLaunchKernelGGL(k_lean_bucket_starts, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk2,
-                       (const u32 *)tfirst.get(), text.b1, n_buckets, (u32)n, bs->start.get());
+    hipLaunchKernelGGL(k_lean_bucket_starts_msd, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk2,
+                       (const u32 *)tfirst.get(), (const u32 *)rstart.get(), text.b2, n_buckets, (u32)kept, (u32)first_rank, bs->start.get());
     hipLaunchKernelGGL(k_bucket_max, dim3(n_buckets / 256), dim3(256), 0, c.stream, bs->start.get(), d_max, n_buckets);
     HIP_CHECK(hipGetLastError());
   }

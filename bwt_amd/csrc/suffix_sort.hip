@@ -2291,7 +2291,8 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 // the second on the top b2 -- leave 2^(b1+b2) buckets of a few thousand suffixes; k_bucket_emit orders a bucket in
 // LDS on the next 16 key bits, settles what those leave tied on the key bits below them and only then on the
 // text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing usable was written.
-static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out) {
+static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out,
+                          LeanShard *shard = nullptr) {
   if (N < c.bucket_min_n || N < 2 || N >= (1ull << 32) - 8) return 0;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
   // Alphabets of 3, 5, 6 or 7 symbols (DNA with N): the codes as digits of a number in that base, scaled to the top of
@@ -2347,25 +2348,34 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   tk.base = base;
   tk.scale = scale;
   tk.lead = lead;
-  DBuf<u64> eb0(c, N), eb1(c, N);
-  u64 *el[2] = {eb0.get(), eb1.get()};
+  DBuf<u64> el[2];
   BucketState bs;
   int cur;
   {
     Phase ph(c, "leaf_radix_sort", (double)N * (1 + 1 + 8 + 8 + 16));
-    cur = leaf_sort_text_lean(c, el, N, BK_CAP, tk, &bs);
+    cur = leaf_sort_text_lean(c, el, N, BK_CAP, tk, &bs, shard);
   }
   if (cur < 0) return 0;
   const u32 n_buckets = 1u << bbits;
   u32 *d_fail = c.d_scalars + 10;
+  // A GPU that holds a share of the leaf (shard) has its elements, its stretch of L and of the suffix array at local
+  // index = leaf rank - first_rank; the bucket bounds are leaf ranks, so the three arrays are addressed from where
+  // rank 0 would lie.
+  const u64 first_rank = shard ? shard->first_rank : 0;
+  const u64 mine = shard ? shard->count : (u64)(b - a);
   DBuf<u32> res;
-  if (sa_out) res = DBuf<u32>(c, (size_t)(b - a));
-  Phase ph(c, "leaf_direct_emit", (double)N * 8 + (double)(b - a) * 2);
+  if (sa_out) res = DBuf<u32>(c, (size_t)(mine ? mine : 1));
+  Phase ph(c, "leaf_direct_emit", (double)mine * 8 + (double)mine * 2);
   LeafEmit<LeanView> em;
   memset(&em, 0, sizeof(em));
   if (E) static_cast<EmitParams &>(em) = *E;
-  em.sa_out = sa_out ? res.get() : nullptr;
-  em.v = LeanView{el[cur], (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16};
+  if (shard && shard->parts > 1 && em.samp) {  // a leaf build: this share's stretch of L is made here, now that its length is known
+    shard->L = DBuf<u8>(c, (size_t)(mine ? mine : 1));
+    em.L = shard->L.get();
+  }
+  if (em.L) em.L -= first_rank;
+  em.sa_out = sa_out ? res.get() - first_rank : nullptr;
+  em.v = LeanView{el[cur].get() - first_rank, (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16};
   em.N = N;
   em.sym_mask = ~0xFFull;  // BucketWindow<LeanView>::key: the ordered key bits above the preceding symbol
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
@@ -2522,15 +2532,61 @@ struct SampCompactOut {
   u32 *rank_out, *pos_out;
   u32 *total;
   size_t n;
+  u32 rank_base = 0;
   __device__ __forceinline__ void operator()(size_t i, u32 ex, u32 in) const {
     if (in != ex) {
       const u64 x = samp[i];
-      rank_out[ex] = (u32)x;
+      rank_out[ex] = (u32)x + rank_base;
       pos_out[ex] = (u32)(x >> 32);
     }
     if (i + 1 == n) *total = in;
   }
 };
+
+i64 compact_sample_slots(Ctx &c, const u64 *slots, i64 n_slots, u32 rank_base, u32 *rank_out, u32 *pos_out) {
+  if (n_slots <= 0) return 0;
+  u32 *d_total = c.d_scalars + 8;
+  scan_generic<u32, SumU32>(c, (size_t)n_slots, SampFilledIn{slots}, SampCompactOut{slots, rank_out, pos_out, d_total, (size_t)n_slots, rank_base});
+  return (i64)read_u32(c, d_total);
+}
+
+bool build_leaf_share(Ctx &c, i64 a, i64 b, i64 ns_req, int part, int parts, LeafShare &out) {
+  const i64 m = b - a;
+  if (!c.T) fail(BWT_HIP_EINVAL, "no text set");
+  if (a < 0 || b > c.n || m < 2 || parts < 1 || part < 0 || part >= parts) fail(BWT_HIP_EINVAL, "bad leaf share %d of %d over [%ld,%ld)", part, parts, (long)a, (long)b);
+  const i64 ns = ns_req < m ? ns_req : m;
+  if (ns < 2) fail(BWT_HIP_EINVAL, "ssa_n_samples must be at least 2 (got %ld)", (long)ns_req);
+  c.wait_text((u64)b + DF_DEPTH + 128);
+  if (window_has_long_repeats(c, a, (u64)m)) return false;
+  out.samp = DBuf<u64>(c, (size_t)ns);
+  out.ns = ns;
+  HIP_CHECK(hipMemsetAsync(out.samp.get(), 0xFF, (size_t)ns * 8, c.stream));
+  u32 *special = c.d_scalars + 16;
+  HIP_CHECK(hipMemsetAsync(special, 0xFF, 8, c.stream));
+  EmitParams E;
+  memset(&E, 0, sizeof(E));
+  E.T = c.T;
+  E.n = (u64)c.n;
+  E.a = (u64)a;
+  E.m = (u64)m;
+  E.ns = ns;
+  E.L = nullptr;  // made by the route once the share's length is known
+  E.samp = out.samp.get();
+  E.special = special;
+  const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
+  const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
+  LeanShard sh;
+  sh.part = part;
+  sh.parts = parts;
+  if (try_lean_route(c, a, b, b, (u64)m, min_sym, span, &E, nullptr, &sh) != 1) return false;
+  out.L = std::move(sh.L);
+  out.bounds = sh.bounds;
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, special, 8, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  out.s_rank = c.h_scalars[0] == 0xFFFFFFFFu ? -1 : (i64)c.h_scalars[0];
+  out.e_rank = c.h_scalars[1] == 0xFFFFFFFFu ? -1 : (i64)c.h_scalars[1];
+  return true;
+}
 
 // bwt_leaf of the reference (include/bwt.h:615-635)
 Block *build_leaf(Ctx &c, i64 a, i64 b, i64 ns_req) {
