@@ -11,7 +11,9 @@ max(2, N) leaves: one leaf per GPU, and two leaves plus their merge on one GPU, 
 path runs there too.  On N GPUs (launched by torch.distributed.run, one rank per GPU) every rank builds its
 leaf and each merge of the tree runs on all GPUs of its subtree (bwt_amd/dist_merge.py): strong scaling of
 one text.  `--leaves 8` gives the 8-leaf tree (3.875e8 suffixes per leaf, 7 merges) on any N that divides 8;
-`--n 1000000000 --leaves 2` is the one-GPU configuration "leaf sort + single gap-array merge".
+`--n 1000000000 --leaves 2` is the one-GPU configuration "leaf sort + single gap-array merge"; `--gpus N --leaves 1`
+builds the text as ONE leaf that the N GPUs share by key range (no merge: the fastest way to N GPUs for a text that
+fits them).
 
 `value` is measured with the text already in HBM and the result left in HBM, the library's timers off; the K
 steps are then repeated with an event pair around every kernel for `roofline` and `phases`.  The same line also
@@ -166,8 +168,9 @@ def main():
             sys.exit(2)
     if args.leaves is None:
         args.leaves = max(2, world)
-    if args.leaves < 1 or args.leaves & (args.leaves - 1) or args.leaves % world:
-        print("--leaves %d: must be a power of two and a multiple of the %d GPUs" % (args.leaves, world), file=sys.stderr)
+    # (one leaf on several GPUs: the GPUs share the leaf by key range, no merge at all)
+    if args.leaves < 1 or args.leaves & (args.leaves - 1) or (args.leaves % world and args.leaves != 1):
+        print("--leaves %d: must be a power of two and a multiple of the %d GPUs (or 1)" % (args.leaves, world), file=sys.stderr)
         sys.exit(2)
 
     import bwt_amd

@@ -69,6 +69,7 @@ def lib():
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dc_sample": [vp, i64, _i64p, _i64p, _i64p, C.POINTER(i32)],
         "bwt_hip_leaf_capacity": [vp, i64, _i64p],
+        "bwt_hip_dist_leaf": [vp, i64, i64, i64, i32, i32, vp, i64, vp, _i64p, _i64p, _i64p, _i64p, _i64p, C.POINTER(i32)],
         "bwt_hip_block_ibwt": [vp, vp, _u8p, _i64p],
         "bwt_hip_block_sa": [vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dist_bounds": [i64, i32, _i64p],
@@ -359,6 +360,18 @@ class Context:
         return gap, g
 
     # ---- one merge spread over several GPUs (raw device addresses) ----------
+    def dist_leaf(self, a, b, ssa_n_samples, part, parts, L_ptr=None, cap=0, slots_ptr=None):
+        """One GPU's share of a leaf cut by key range over `parts` GPUs: None if the leaf does not take the route, else
+        dict(first_rank, count, s_rank, e_rank, bounds)."""
+        fr, cnt, sr, er = C.c_int64(0), C.c_int64(0), C.c_int64(-1), C.c_int64(-1)
+        bounds = np.zeros(parts + 1, dtype=np.int64)
+        ok = C.c_int32(0)
+        _chk(lib().bwt_hip_dist_leaf(self._h, a, b, ssa_n_samples, part, parts, L_ptr, cap, slots_ptr, C.byref(fr), C.byref(cnt),
+                                     C.byref(sr), C.byref(er), _p(bounds, _i64p), C.byref(ok)))
+        if not ok.value:
+            return None
+        return {"first_rank": fr.value, "count": cnt.value, "s_rank": sr.value, "e_rank": er.value, "bounds": bounds}
+
     def dist_chains(self, l, ra, rb, build_gap_segment_sz, g_ptr):
         _chk(lib().bwt_hip_dist_chains(self._h, l._h, ra, rb, build_gap_segment_sz, C.c_void_p(g_ptr)))
 

@@ -928,6 +928,32 @@ int bwt_hip_dist_merge_slice_grouped(bwt_hip_ctx *ctx, const uint8_t *lL_dev, in
   API_END
 }
 
+int bwt_hip_dist_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ns, int part, int parts, uint8_t *L_dev, int64_t cap,
+                      uint64_t *slots_dev, int64_t *first_rank, int64_t *count, int64_t *s_rank, int64_t *e_rank,
+                      int64_t *bounds, int *applies) {
+  API_BEGIN
+  need(ctx && first_rank && count && s_rank && e_rank && applies, "ctx, first_rank, count, s_rank, e_rank, applies");
+  need(parts >= 1 && parts <= 256 && part >= 0 && part < parts, "0 <= part < parts <= 256");
+  Ctx &c = ctx->c;
+  HIP_CHECK(hipSetDevice(c.device));
+  LeafShare sh;
+  *applies = build_leaf_share(c, a, b, ns, part, parts, sh) ? 1 : 0;
+  if (*applies) {
+    const i64 lo = (i64)sh.bounds[(size_t)part], cnt = (i64)sh.bounds[(size_t)part + 1] - lo;
+    need(!L_dev || cnt <= cap, "cap: room for this share of L");
+    *first_rank = lo;
+    *count = cnt;
+    *s_rank = sh.s_rank;
+    *e_rank = sh.e_rank;
+    if (bounds)
+      for (int j = 0; j <= parts; j++) bounds[j] = (int64_t)sh.bounds[(size_t)j];
+    if (L_dev && cnt > 0) HIP_CHECK(hipMemcpyAsync(L_dev, sh.L.get(), (size_t)cnt, hipMemcpyDeviceToDevice, c.stream));
+    if (slots_dev) HIP_CHECK(hipMemcpyAsync(slots_dev, sh.samp.get(), (size_t)sh.ns * 8, hipMemcpyDeviceToDevice, c.stream));
+    c.sync();
+  }
+  API_END
+}
+
 int bwt_hip_dist_chains(bwt_hip_ctx *ctx, bwt_hip_block *l_, int64_t ra, int64_t rb, int64_t seg, uint32_t *g_dev) {
   API_BEGIN
   need(ctx && l_ && g_dev, "ctx, l, g_dev");

@@ -290,6 +290,10 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   const u32 wbase = w * RS_PER_WAVE;
   u32 *myc = cnt[w];  // this wave's counters: no other wave touches them before the barrier
   u32 dig[RS_ITEMS], rk[RS_ITEMS];
+  // A text pass that keeps only the digits keep_lo .. keep_hi-1 (a leaf shared by several GPUs): the others are neither
+  // ranked nor staged, the tile shrinks to what is kept (tile_kept).
+  const bool filt = REVERSE && sizeof(K) == 8 && !HAS_VALS && !SIDE && keep_hi != 0;
+  u32 keepm = ~0u, tile_kept = tile_n;
   if constexpr (ANY_ORDER) {
     u32 *all = cnt[0];  // one row of counters for the whole tile
     if (tid < (u32)DIG) all[tid] = 0;
@@ -298,7 +302,12 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     for (int r = 0; r < RS_ITEMS; r++) {
       dig[r] = digit_of<K>(key[r], shift, mask);
       rk[r] = 0;
-      if (FULL || wbase + r * 64 + lane < tile_n) rk[r] = atomicAdd(&all[dig[r]], 1u);
+      bool valid = FULL || wbase + r * 64 + lane < tile_n;
+      if (filt && (dig[r] < keep_lo || dig[r] >= keep_hi)) {
+        valid = false;
+        keepm &= ~(1u << r);
+      }
+      if (valid) rk[r] = atomicAdd(&all[dig[r]], 1u);
     }
     lds_barrier();
     const u32 tot = tid < (u32)DIG ? all[tid] : 0u;
@@ -311,7 +320,9 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       dstart[tid] = REVERSE ? ds + tot - 1 : ds;
       gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
     }
+    if (filt && tid == (u32)DIG - 1) scan_s[16] = incl;  // what the tile keeps
     lds_barrier();
+    if (filt) tile_kept = scan_s[16];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) rk[r] = REVERSE ? dstart[dig[r]] - rk[r] : dstart[dig[r]] + rk[r];
   } else {
@@ -371,7 +382,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   lds_barrier();  // counters are dead from here: the buffer becomes the staging area
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    if (FULL || wbase + r * 64 + lane < tile_n) {
+    if ((FULL || wbase + r * 64 + lane < tile_n) && ((keepm >> r) & 1u)) {
       keys_s[rk[r]] = key[r];
       if (HAS_VALS) vals_s[rk[r]] = val[r];
       if constexpr (SIDE) side_s[rk[r]] = sd[r];
@@ -381,7 +392,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const u32 p = r * RS_THREADS + tid;
-    if (FULL || p < tile_n) {
+    if ((FULL && !filt) || p < tile_kept) {
       K k = keys_s[p];
       const u32 dg = digit_of<K>(k, shift, mask);
       if constexpr (REVERSE && sizeof(K) == 8 && !HAS_VALS && !SIDE) {
@@ -1022,31 +1033,45 @@ __global__ void k_lean_bucket_starts(const u32 *__restrict__ offs2, u32 nblk2, c
 // is region, then second digit): the offsets of its tile counts, [digit][tile], are therefore scanned per region -- all
 // tiles of the region's digit 0, then digit 1, ... -- from the region's first element on, in place.  One workgroup per
 // region; every wave sums, then scans, the digits it owns, so that no barrier separates the digits.
-constexpr int LR_THREADS = 512;
-__global__ void __launch_bounds__(LR_THREADS) k_lean_region_scan(u32 *__restrict__ counts, u32 nblk2, const u32 *__restrict__ tfirst,
-                                                                 const u32 *__restrict__ rstart, u32 ndig) {
-  __shared__ u32 tot_s[1024];
-  __shared__ u32 scan_s[17];
-  const u32 r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = LR_THREADS / 64;
+constexpr int LR_THREADS = 256;
+constexpr u32 LR_DIGITS = 32;  // digits per workgroup (eight per wave)
+
+// tot[r * ndig + d] = elements of digit d in region r (a wave per digit)
+__global__ void __launch_bounds__(LR_THREADS) k_lean_region_sums(const u32 *__restrict__ counts, u32 nblk2, const u32 *__restrict__ tfirst,
+                                                                 u32 ndig, u32 *__restrict__ tot) {
+  const u32 chunks = ndig / LR_DIGITS, r = blockIdx.x / chunks, d0 = (blockIdx.x % chunks) * LR_DIGITS;
+  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const u32 t0 = tfirst[r], t1 = tfirst[r + 1];
-  if (t0 == t1) return;
-  for (u32 d = w; d < ndig; d += nw) {
+  for (u32 d = d0 + w; d < d0 + LR_DIGITS; d += LR_THREADS / 64) {
     u32 sum = 0;
     for (u32 t = t0 + lane; t < t1; t += 64) sum += counts[(size_t)d * nblk2 + t];
     sum = wave_reduce_sum(sum);
-    if (lane == 0) tot_s[d] = sum;
+    if (lane == 0) tot[(size_t)r * ndig + d] = sum;
+  }
+}
+
+// the scan itself: a workgroup takes LR_DIGITS digits of a region, starting where the digits below them end
+__global__ void __launch_bounds__(LR_THREADS) k_lean_region_scan(u32 *__restrict__ counts, u32 nblk2, const u32 *__restrict__ tfirst,
+                                                                 const u32 *__restrict__ rstart, u32 ndig, const u32 *__restrict__ tot) {
+  __shared__ u32 base_s[LR_DIGITS];
+  __shared__ u32 scan_s[17];
+  const u32 chunks = ndig / LR_DIGITS, r = blockIdx.x / chunks, d0 = (blockIdx.x % chunks) * LR_DIGITS;
+  const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 t0 = tfirst[r], t1 = tfirst[r + 1];
+  if (t0 == t1) return;
+  // elements of the region's digits below d0, then the exclusive sums of this workgroup's own digits
+  u32 below = 0;
+  for (u32 d = tid; d < d0; d += LR_THREADS) below += tot[(size_t)r * ndig + d];
+  u32 all_below;
+  block_scan_incl<OpSum>(below, scan_s, &all_below);
+  if (tid < 64) {
+    const u32 v = tid < LR_DIGITS ? tot[(size_t)r * ndig + d0 + tid] : 0u;
+    const u32 in = wave_scan_incl_sum(v);
+    if (tid < LR_DIGITS) base_s[tid] = rstart[r] + all_below + in - v;
   }
   __syncthreads();
-  // exclusive prefix sums of the digits' totals (ndig <= 1024 = two values per thread)
-  const u32 a = 2 * tid < ndig ? tot_s[2 * tid] : 0u, b = 2 * tid + 1 < ndig ? tot_s[2 * tid + 1] : 0u;
-  u32 all;
-  const u32 incl = block_scan_incl<OpSum>(a + b, scan_s, &all);
-  __syncthreads();
-  if (2 * tid < ndig) tot_s[2 * tid] = rstart[r] + incl - a - b;
-  if (2 * tid + 1 < ndig) tot_s[2 * tid + 1] = rstart[r] + incl - b;
-  __syncthreads();
-  for (u32 d = w; d < ndig; d += nw) {
-    u32 run = tot_s[d];
+  for (u32 d = d0 + w; d < d0 + LR_DIGITS; d += LR_THREADS / 64) {
+    u32 run = base_s[d - d0];
     for (u32 tb = t0; tb < t1; tb += 64) {
       const u32 t = tb + lane;
       const u32 v = t < t1 ? counts[(size_t)d * nblk2 + t] : 0u;
@@ -1130,7 +1155,12 @@ static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk
   }
   {
     KernelTimer kt(c, "leaf:k_lean_region_scan", (double)(1 << DB) * nblk2 * 12);
-    hipLaunchKernelGGL(k_lean_region_scan, dim3(1u << tk.b1), dim3(LR_THREADS), 0, c.stream, counts, nblk2, tfirst, rstart, (u32)(1 << DB));
+    constexpr u32 ndig = 1u << DB;
+    static_assert(ndig % LR_DIGITS == 0 && LR_DIGITS <= 64, "whole chunks of digits; one wave scans a chunk's totals");
+    const u32 regions = 1u << tk.b1, grid = regions * (ndig / LR_DIGITS);
+    DBuf<u32> tot(c, (size_t)regions * ndig);
+    hipLaunchKernelGGL(k_lean_region_sums, dim3(grid), dim3(LR_THREADS), 0, c.stream, (const u32 *)counts, nblk2, tfirst, ndig, tot.get());
+    hipLaunchKernelGGL(k_lean_region_scan, dim3(grid), dim3(LR_THREADS), 0, c.stream, counts, nblk2, tfirst, rstart, ndig, (const u32 *)tot.get());
     HIP_CHECK(hipGetLastError());
   }
   KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
@@ -1215,15 +1245,13 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
   const u32 nblk = ceil_div(n, RS_TILE);
   const u32 nd1 = 1u << text.b1, n_buckets = 1u << bbits;
-  const u32 nblk2 = nblk + nd1 + 1;
   TextKeys first = text;
   first.next_digits = nullptr;
   TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
   // (not with digits of another base: there every symbol of the key can reach the top bits)
   if (!text.base && count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
-  DBuf<u32> counts(c, (size_t)(text.b2 > 9 ? 1024 : 512) * nblk2);
+  DBuf<u32> counts(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
   DBuf<u32> tfirst(c, nd1 + 1), rstart(c, nd1 + 1);
-  DBuf<uint2> tmap(c, nblk2);
   if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
   else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
   const u32 dig1 = text.b1 > 8 ? 512u : 256u;  // counter rows of the text pass
@@ -1264,6 +1292,8 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   } else if (shard) {
     shard->first_rank = 0;
     shard->count = n;
+    shard->bounds.assign(2, 0);
+    shard->bounds[1] = n;
   }
   scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, nullptr);
   const size_t room = kept > 0 ? kept : 1;
@@ -1277,12 +1307,17 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   }
   if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, counts.get());
   else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, counts.get());
+  // the second pass's tiles: those of what was kept, cut at the regions' ends (at most one short tile per region)
+  const u32 nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
+  DBuf<uint2> tmap(c, nblk2);
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
                      tmap.get(), nblk2, rstart.get());
   HIP_CHECK(hipGetLastError());
-  if (text.b2 > 9) lean_second_pass<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
-  else if (text.b2 > 8) lean_second_pass<9>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
-  else lean_second_pass<8>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts.get(), tmap.get(), digits.get(), tfirst.get(), rstart.get());
+  DBuf<u32> counts2(c, (size_t)(text.b2 > 9 ? 1024 : (text.b2 > 8 ? 512 : 256)) * nblk2);
+  if (text.b2 > 9) lean_second_pass<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
+  else if (text.b2 > 8) lean_second_pass<9>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
+  else lean_second_pass<8>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), digits.get(), tfirst.get(), rstart.get());
+  counts = std::move(counts2);
   bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
   u32 *d_max = c.d_scalars + 12;
   {

@@ -2369,7 +2369,7 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   LeafEmit<LeanView> em;
   memset(&em, 0, sizeof(em));
   if (E) static_cast<EmitParams &>(em) = *E;
-  if (shard && shard->parts > 1 && em.samp) {  // a leaf build: this share's stretch of L is made here, now that its length is known
+  if (shard && em.samp) {  // a leaf build: this share's stretch of L is made here, now that its length is known
     shard->L = DBuf<u8>(c, (size_t)(mine ? mine : 1));
     em.L = shard->L.get();
   }

@@ -209,9 +209,10 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     n = args.n
     ctx = bwt_amd.Context(local_rank)
     ctx.gen_text(n, 42, args.sigma)
-    assert args.leaves % world == 0 and args.leaves & (args.leaves - 1) == 0, "--leaves: a power of two, a multiple of the GPUs"
-    lpr = args.leaves // world
-    total_leaves = world * lpr
+    assert args.leaves & (args.leaves - 1) == 0 and (args.leaves % world == 0 or args.leaves == 1), "--leaves: a power of two, a multiple of the GPUs (or 1)"
+    one_leaf = args.leaves == 1 and world > 1  # the GPUs share the one leaf by key range (bwt_hip_dist_leaf): native schedule only
+    lpr = max(1, args.leaves // world)
+    total_leaves = 1 if one_leaf else world * lpr
     depth = total_leaves.bit_length() - 1
     ns = args.ssa_n_samples or max(1000, int(0.4 * n / (1 + max(1, depth)) / 16))
     # "native" (default): every merge runs on all GPUs of its subtree and the result stays spread over the GPUs, the
@@ -219,6 +220,8 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     # Python over torch.distributed (bwt_amd/dist_merge.py; its g values travel as 32-bit words); "tree": right blocks
     # move to the left owner, the result ends on rank 0
     algo = os.environ.get("BWT_MGPU_ALGO", "native")
+    if one_leaf and algo != "native":
+        raise SystemExit("--leaves 1 on several GPUs needs the native schedule (BWT_MGPU_ALGO=native)")
     transport, fallback = None, None
     if algo == "native":
         # the library's communicator comes up on every rank or the run takes the torch.distributed schedule instead:
@@ -331,14 +334,18 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             "data": "synthetic (splitmix64 seed 42, T[i]=1+x%%%d, 0-terminated), generated on every device" % args.sigma,
             "value_definition": "(n-1) / seconds per build (slowest rank, between barriers), the text resident in every GPU's HBM before the timed region, L left sliced over the GPUs, library timers off",
             "ms_per_step_with_kernel_timers": round(dt_timers * 1e3, 3) if dt_timers else None,
-            "config": {"workload": ("random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
+            "config": {"workload": ("random DNA n=%d as %d leaf shared by %d MI355X by key range (every GPU reads the whole text and sorts "
+                                    "its stretch of first key digits; no merge); L stays sliced over the GPUs, every GPU keeps a stretch of the sample slots"
+                                    if one_leaf else
+                                    "random DNA n=%d, %d leaves sharded over %d MI355X, every merge spread over the GPUs of its "
                                     "subtree (RCCL send/recv); L stays sliced over the GPUs, every GPU keeps the samples of its own text range"
                                     if algo in ("dist", "native") else
                                     "random DNA n=%d, %d leaves sharded over %d MI355X, merge tree over RCCL send/recv; result on rank 0")
                                    % (n, total_leaves, world),
                        "n": n, "sigma": args.sigma, "leaves": total_leaves, "bwt_rec_threshold": th, "ssa_n_samples": ns,
                        "build_gap_segment_sz": args.seg or 1024, "text_resident_in_hbm": True,
-                       "parallelism": "leaf-sharded x%d, %s" % (world, {"dist": "distributed merges (torch.distributed)",
+                       "parallelism": ("one leaf cut by key range x%d (C++ driver; RCCL carries the special ranks and the sample slots)" % world) if one_leaf else
+                                      "leaf-sharded x%d, %s" % (world, {"dist": "distributed merges (torch.distributed)",
                                                                         "native": "distributed merges (C++ driver, RCCL send/recv)"}.get(algo, "pairwise merge tree"))},
             # rank 0's own kernels (it builds one leaf and does the left half of every merge level)
             "roofline": roofline(timers), "cpu_baseline": None, "schedule": algo, "native_transport_fallback": fallback,

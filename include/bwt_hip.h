@@ -299,6 +299,21 @@ int bwt_hip_dist_samples_place(bwt_hip_ctx *ctx, int is_left, const uint32_t *ra
                                int64_t first_index, int64_t n_all, int64_t ssa_n_samples_out, uint32_t *o_rank_dev,
                                uint32_t *o_pos_dev, int64_t *kept);
 
+/* bwt::bwt_leaf (include/bwt.h:615-635) of T[a:b) shared by `parts` GPUs, cut by KEY RANGE: every GPU reads the whole
+   text and builds the stretch of the leaf's suffix order whose sort keys begin with its share of first digits.  The
+   shares are cut into about equal numbers of suffixes by every GPU from its own count over the text -- the same cut
+   everywhere, nothing exchanged -- so GPU `part` ends up with the ranks [*first_rank, *first_rank + *count) of the
+   leaf (relative to a): L_dev receives that stretch of L (up to cap symbols; a larger share fails with BWT_HIP_EINVAL),
+   slots_dev (min(b-a, ssa_n_samples) entries, may be null) the leaf's position-ordered sample slots as
+   (position << 32 | leaf rank), filled where the sampled suffix belongs to this share and all ones elsewhere;
+   *s_rank / *e_rank are -1 where another share holds that suffix; bounds (parts + 1 entries, may be null) receives
+   every share's first rank.  *applies = 0 (and nothing else written): the leaf does not take the route this needs
+   (the lean bucket route: 1e8 suffixes and more, no long repeats); it is then built whole, or as a tree.
+   bwt_hip_dist_pmbwt does this when its tree is a single leaf. */
+int bwt_hip_dist_leaf(bwt_hip_ctx *ctx, int64_t a, int64_t b, int64_t ssa_n_samples, int part, int parts, uint8_t *L_dev,
+                      int64_t cap, uint64_t *slots_dev, int64_t *first_rank, int64_t *count, int64_t *s_rank,
+                      int64_t *e_rank, int64_t *bounds, int *applies);
+
 /* ---- the whole build over several GPUs -------------------------------------------------------------- */
 /* The reference builds in one address space.  Here the recursion tree of bwt::bwt_rec (include/bwt.h:854-865) is cut
    at depth log2(world): rank k builds the k-th subtree on its own GPU, and every merge above (include/bwt.h:791-847)
@@ -340,7 +355,9 @@ void bwt_hip_transport_free(bwt_hip_transport *t);
 typedef struct bwt_hip_slice bwt_hip_slice;
 /* bwt::pmbwt (include/bwt.h:867-883) over t->world ranks (a power of two); called by every rank with its own
    context, all of which hold the same text.  The tree is the reference's for this bwt_rec_threshold; it must have
-   at least `world` leaves at depth log2(world) (BWT_HIP_EINVAL otherwise). */
+   at least `world` leaves at depth log2(world) (BWT_HIP_EINVAL otherwise) -- or be a single leaf
+   (bwt_rec_threshold >= n), which the ranks then share by key range (bwt_hip_dist_leaf: no merge at all; rank k ends
+   up with slice k of L and the samples of the k-th stretch of sample slots). */
 int bwt_hip_dist_pmbwt(bwt_hip_ctx *ctx, bwt_hip_transport *t, int64_t bwt_rec_threshold, int64_t ssa_n_samples,
                        int64_t build_gap_segment_sz, bwt_hip_slice **out);
 /* first: rank of the slice's first symbol; s_rank / e_rank as bwt_hip_block_info, -1 on the ranks that do not
