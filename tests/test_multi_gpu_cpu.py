@@ -120,3 +120,41 @@ def test_gloo_distributed_merge_with_grouped_g_exchange(tmp_path):
     r, p = ob.samples()
     assert (res["rank"] == r).all() and (res["pos"] == p).all()
     assert res["sizes"][0] % 8192 != 0 and int(res["sizes"].sum()) == n  # (the cut is at a multiple of 8192 LEFT ranks)
+
+
+def test_key_range_cuts_cover_and_balance():
+    """The cut of one leaf over several ranks by first key digit: stretches of digits that cover everything once, with
+    about equal counts where no single digit is heavy, and the same for every caller (it depends on the counts only)."""
+    from bwt_amd import dist_leaf
+    rng = np.random.default_rng(5)
+    for nd, parts in ((512, 2), (512, 8), (256, 4), (16, 8)):
+        counts = rng.integers(0, 1000, size=nd)
+        cuts, bounds = dist_leaf.key_range_cuts(counts, parts)
+        assert cuts[0] == 0 and cuts[-1] == nd and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert bounds[0] == 0 and bounds[-1] == counts.sum()
+        if nd >= 256:
+            sizes = np.diff(bounds)
+            assert sizes.max() - sizes.min() <= 2 * counts.max()
+    # one digit holds nearly everything: some parts are empty, nothing is lost
+    counts = np.array([1, 2, 1000000, 3, 4])
+    cuts, bounds = dist_leaf.key_range_cuts(counts, 4)
+    assert bounds[-1] == counts.sum() and sorted(bounds) == bounds
+
+
+@pytest.mark.parametrize("world,sigma", [(2, 4), (4, 26)])
+def test_gloo_one_leaf_by_key_range(tmp_path, world, sigma):
+    """The one-leaf schedule over gloo with numpy shares: slices of L in rank order and the exchanged sample slots
+    equal the oracle's leaf of the whole text."""
+    n, ns = 20000, 300
+    out = str(tmp_path / "leaf.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(31500 + os.getpid() % 2000),
+           os.path.join(ROOT, "tests", "dist_leaf_worker.py"), "--out", out, "--text_len", str(n), "--ns", str(ns), "--sigma", str(sigma)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    res = np.load(out)
+    T = gen_text(n, 42, sigma)
+    ob = Oracle.pmbwt(T, Oracle.opt(n, alpha_min=1, alpha_max=sigma, bwt_rec_threshold=n, ssa_n_samples=ns))
+    assert (res["L"] == ob.L).all()
+    r, p_ = ob.samples()
+    assert (res["samp_pos"] == p_).all() and (res["samp_rank"] == r).all()
