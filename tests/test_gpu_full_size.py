@@ -328,3 +328,23 @@ def test_config3_n3_1e9_eight_ranks_share_the_gpu(ctx):
     assert used == 8 and (s_rank, e_rank) == info1
     assert h8(L) == f1
     assert len(r) == len(r1) and (r == r1).all() and (p == p1).all()
+
+
+def test_n3_1e9_one_leaf_over_eight_ranks_by_key_range(ctx):
+    """One leaf of 3.1e9 symbols cut over 8 ranks by key range (threads that share the one GPU; every rank counts the
+    whole text, keeps its stretch of first key digits and builds that slice of L, and the sample slots go once round
+    all ranks): L, the special ranks and the samples equal the single-GPU build of the same one-leaf tree."""
+    import bwt_amd
+    n, ns = 3100000000, 19375000
+    ctx.gen_text(n, 42, 4)
+    one = ctx.pmbwt(n, ns)
+    f1, info1 = h8(one.L), (one.s_rank, one.e_rank)
+    r1, p1 = one.samples()
+    one.free()
+    T = ctx.get_text()
+    ctx.trim()
+    L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * 8, T, n, ns)
+    del T
+    assert used == 8 and (s_rank, e_rank) == info1
+    assert h8(L) == f1
+    assert len(r) == len(r1) and (r == r1).all() and (p == p1).all()
