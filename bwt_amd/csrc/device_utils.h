@@ -121,4 +121,22 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The listed stretch (start, end, period p: T[j] = T[j-p] for start + p <= j < end) that holds x with at least its
+// period behind x inside it: *end_out and the period, 0 if there is none.  runs: n_runs starts, ends, periods.
+constexpr u32 RUN_PERIOD_MAX = 8;
+__device__ __forceinline__ u32 run_around(const u32 *__restrict__ runs, u32 n_runs, u64 x, u64 *end_out) {
+  if (x < RUN_PERIOD_MAX) return 0;
+  u32 lo = 0, hi = n_runs;  // the last stretch that starts at or below x - RUN_PERIOD_MAX
+  while (lo < hi) {
+    const u32 mid = (lo + hi) / 2;
+    if ((u64)runs[mid] <= x - RUN_PERIOD_MAX) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo == 0) return 0;
+  const u64 end = runs[n_runs + lo - 1];
+  if (x >= end || x < (u64)runs[lo - 1] + RUN_PERIOD_MAX) return 0;
+  *end_out = end;
+  return runs[2 * n_runs + lo - 1];
+}
+
 }  // namespace bwtamd

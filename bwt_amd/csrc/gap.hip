@@ -54,24 +54,6 @@ struct ChainParams {
   DcView dc;
 };
 
-// The listed stretch (start, end, period p: T[j] = T[j-p] for start + p <= j < end) that holds x with at least its
-// period behind x inside it: *end_out and the period, 0 if there is none.  runs: n_runs starts, ends, periods.
-constexpr u32 RUN_PERIOD_MAX = 8;
-__device__ __forceinline__ u32 run_around(const u32 *__restrict__ runs, u32 n_runs, u64 x, u64 *end_out) {
-  if (x < RUN_PERIOD_MAX) return 0;
-  u32 lo = 0, hi = n_runs;  // the last stretch that starts at or below x - RUN_PERIOD_MAX
-  while (lo < hi) {
-    const u32 mid = (lo + hi) / 2;
-    if ((u64)runs[mid] <= x - RUN_PERIOD_MAX) lo = mid + 1;
-    else hi = mid;
-  }
-  if (lo == 0) return 0;
-  const u64 end = runs[n_runs + lo - 1];
-  if (x >= end || x < (u64)runs[lo - 1] + RUN_PERIOD_MAX) return 0;
-  *end_out = end;
-  return runs[2 * n_runs + lo - 1];
-}
-
 // T[x:] < T[y:] for x != y, both < n (the unique 0 at n-1 ends the loop).  Eight symbols per (unaligned) load
 // while both suffixes have eight left: on repetitive texts these comparisons run for thousands of symbols.
 // Runs of one symbol (the N of an assembly's gaps, millions long) and other stretches of a short period would make
@@ -619,7 +601,8 @@ __global__ void __launch_bounds__(256) k_periodic_blocks(const u8 *__restrict__ 
 }
 
 // runs[i], runs[count + i], runs[2 * count + i]: S, E, p with T[j] = T[j+p] for S <= j < E on entry; on exit the
-// stretch [start, end) that rule extends to (by at most RUN_BLOCK + 8 positions each way)
+// stretch [start, end) that rule extends to (by at most RUN_BLOCK + 8 positions each way), and its last symbol in
+// runs[3 * count + i]
 __global__ void k_extend_runs(const u8 *__restrict__ T, u64 n, u32 count, u32 *__restrict__ runs) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * count) return;
@@ -633,6 +616,7 @@ __global__ void k_extend_runs(const u8 *__restrict__ T, u64 n, u32 count, u32 *_
     u64 e = runs[count + i];
     for (u32 k = 0; k < RUN_BLOCK + 8 && e + p < n && T[e] == T[e + p]; k++) e++;
     runs[count + i] = (u32)(e + p);  // T[j] = T[j-p] for start + p <= j < e + p
+    runs[3 * count + i] = T[runs[count + i] - 1];  // (of a run of one symbol: that symbol)
   }
 }
 
@@ -676,11 +660,12 @@ void ensure_run_table(Ctx &c) {
   if (count == 0) return;
   first.insert(first.end(), last.begin(), last.end());
   first.insert(first.end(), period.begin(), period.end());
-  c.runs = (u32 *)c.alloc((size_t)count * 3 * sizeof(u32));
-  HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 3 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+  first.resize((size_t)count * 4, 0);
+  c.runs = (u32 *)c.alloc((size_t)count * 4 * sizeof(u32));
+  HIP_CHECK(hipMemcpyAsync(c.runs, first.data(), (size_t)count * 4 * sizeof(u32), hipMemcpyHostToDevice, c.stream));
   hipLaunchKernelGGL(k_extend_runs, dim3(ceil_div(2 * count, 64)), dim3(64), 0, c.stream, c.T, (u64)c.n, count, c.runs);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemcpyAsync(first.data(), c.runs, (size_t)count * 3 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipMemcpyAsync(first.data(), c.runs, (size_t)count * 4 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
   c.sync();  // `first` is on the stack
   c.n_runs = count;
   c.runs_host = std::move(first);

@@ -124,7 +124,7 @@ struct Ctx {
   bool defer_chains = true;
   // Long stretches of T that repeat a unit of at most 8 symbols (runs of one symbol above all; every such stretch that
   // holds a whole aligned 4096-symbol block), found on the first merge of a text: the chains' suffix comparisons step
-  // over them (gap.hip).  n_runs starts, then n_runs ends (exclusive), then n_runs periods.
+  // over them (gap.hip).  n_runs starts, then n_runs ends (exclusive), then n_runs periods, then n_runs last symbols.
   u32 *runs = nullptr;
   u32 n_runs = 0;
   std::vector<u32> runs_host;  // the same list on the host (the leaf sort sizes its window by it)
@@ -132,6 +132,7 @@ struct Ctx {
   bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
   bool repeat_probe = true;
+  bool run_filter = true;  // long runs of one symbol leave the lean route's sort and are ranked in closed form (off: tests)
   // Ranks of a difference-cover sample of the whole text (DcSample below), built on first use by a leaf whose ties are
   // dense: 0 never, 1 when a leaf asks for them, 2 for every leaf that has ties at all (tests)
   int dc_mode = 1;
@@ -312,6 +313,17 @@ struct TextKeys {
   // keep_hi != 0 (lean text pass of a leaf that is spread over several GPUs): only the elements whose first digit lies
   // in [keep_lo, keep_hi) are written
   u32 keep_lo, keep_hi;
+  // run_span != 0 (lean text pass of a window with long runs of one symbol): the suffixes whose key lies in
+  // [run_lo, run_lo + run_span) -- those that begin with run_k copies of that symbol -- are left out of the sort (their
+  // order is known in closed form, suffix_sort.hip); low byte of run_lo zero
+  u64 run_lo, run_span;
+  // ... and whose first run_k symbols really are run_sym (a key alone cannot always tell: the terminator, or
+  // code_max).  code_max != 0 (bit-field codes only): the run symbol, the alphabet's largest and rare outside its
+  // runs, has no code of its own, so that the keys use the key space of the alphabet without it: where it stands a
+  // key shows code_max, the code of the symbol below it, and the same for every symbol behind it -- "that symbol,
+  // then nothing larger" -- which keeps the keys in the order of the suffixes; equal keys then need not be equal
+  // symbols.
+  u32 run_sym, run_k, code_max;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).
@@ -347,7 +359,10 @@ struct LeanShard {
   std::vector<u64> bounds;  // out: leaf rank of every part's first suffix, parts + 1 entries (the same on every GPU)
   DBuf<u8> L;               // out (leaf builds that ask for L): this part's stretch of L, `count` symbols
 };
-int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard = nullptr);
+int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard = nullptr,
+                        size_t *kept_out = nullptr);
+// symbols of the key that the lean text pass's histogram rolls (what TextKeys::run_lo / run_span may be cut from)
+int lean_count_symbols(const TextKeys &text);
 int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit, int use = 1);
 // The gap histogram's grouping: the values of keys[0] grouped by their bits [low, low + b1 + b2), in two passes
 // that keep neither digit; afterwards keys[0] holds the values' low `low` bits as 16-bit words, bucket k of them

@@ -89,6 +89,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   const u64 maskall = (1ull << used) - 1;
   const int lsh = 64 - used;
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
+  const u32 cm = tk.code_max ? tk.code_max : 0xFFu;  // (TextKeys::code_max)
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
   const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
   if (w == 2 && !tk.one_based && !tk.base && K0 + ITEMS <= 32) {
@@ -107,6 +108,10 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
         const u32 x = src[q];
         if (q < WORDS / 2 + 1) wds[q] = x;
         plain = plain && !((x - 0x01010101u) & ~x & 0x80808080u);
+        if (tk.code_max) {  // a symbol whose code is not c - min_sym: the byte loop
+          const u32 z = x ^ (tk.run_sym * 0x01010101u);
+          plain = plain && !((z - 0x01010101u) & ~z & 0x80808080u);
+        }
         const u32 y = x - tk.min_sym * 0x01010101u;
         codes = (codes << 8) | (((y & 0x03030303u) * 0x40100401u) >> 24);
       }
@@ -131,32 +136,48 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
     for (int k = 0; k < K0; k++) {
       if ((k & 3) == 0) wd = src[k >> 2];
       const u32 ch = wd & 255u;
-      sf = sf * B + (ch ? ch - ms : 0u);
+      sf = sf * B + (ch ? min(ch - ms, cm) : 0u);
       wd >>= 8;
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
       key_out[j] = ((sf * tk.scale) << 8) | raw[j - 1];
       const u32 out = raw[j], in = raw[K0 + j];
-      sf = (sf - (u64)(out ? out - ms : 0u) * tk.lead) * B + (in ? in - ms : 0u);
+      sf = (sf - (u64)(out ? min(out - ms, cm) : 0u) * tk.lead) * B + (in ? min(in - ms, cm) : 0u);
     }
     return;
   }
+  // code_max: which of the key's symbols are the one that shares a code (bit k: the k-th) -- behind the first of
+  // them the key shows the largest codes only, whatever follows (TextKeys::code_max)
+  u64 shared = 0;
   for (int k = 0; k < K0; k++) {
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
-    sf = (sf << w) | (ch ? ch - ms : 0u);
+    sf = (sf << w) | (ch ? min(ch - ms, cm) : 0u);
+    if (tk.code_max) shared |= (u64)(ch == tk.run_sym) << k;
     wd >>= 8;
   }
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    key_out[j] = (sf << lsh) | raw[j - 1];  // the preceding symbol as it is
+    u64 field = sf;
+    if (tk.code_max && shared) field |= (1ull << (used - w * (__builtin_ctzll(shared) + 1))) - 1ull;
+    key_out[j] = (field << lsh) | raw[j - 1];  // the preceding symbol as it is
     const int k = K0 + j;
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
-    sf = ((sf << w) | (ch ? ch - ms : 0u)) & maskall;
+    sf = ((sf << w) | (ch ? min(ch - ms, cm) : 0u)) & maskall;
+    if (tk.code_max) shared = (shared >> 1) | ((u64)(ch == tk.run_sym) << (K0 - 1));
     wd >>= 8;
   }
+}
+
+// Is the suffix at tile index idx, whose key has been rolled, left out of the sort (TextKeys::run_span)?
+__device__ __forceinline__ bool tk_left_out(const u32 *S32, u32 idx, u64 key, const TextKeys &tk) {
+  if (!((key & ~0xFFull) - tk.run_lo < tk.run_span)) return false;  // (run_span 0: never)
+  const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + idx;
+  for (u32 j = 0; j < tk.run_k; j++)
+    if (raw[j] != tk.run_sym) return false;
+  return true;
 }
 
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
@@ -182,7 +203,7 @@ __global__ void __launch_bounds__(RH_THREADS)
 #pragma unroll
     for (int r = 0; r < RH_ITEMS; r++) {
       u32 d = (u32)(key[r] >> shift) & mask;
-      if (tile0 + tid * RH_ITEMS + r < n) atomicAdd(&cnt[w][d], 1u);
+      if (tile0 + tid * RH_ITEMS + r < n && !tk_left_out(stage, tid * RH_ITEMS + r, key[r], tk)) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
     for (u32 d = tid; d < (u32)DIG; d += RH_THREADS) {
@@ -280,7 +301,8 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 u8 *__restrict__ next_digits = nullptr, int next_shift = 0,
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
                                                 u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
-                                                u32 lean_tile0 = 0, u32 narrow_mask = 0, u32 keep_lo = 0, u32 keep_hi = 0) {
+                                                u32 lean_tile0 = 0, u32 narrow_mask = 0, u32 keep_lo = 0, u32 keep_hi = 0,
+                                                u32 dropm = 0) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -290,8 +312,9 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   const u32 wbase = w * RS_PER_WAVE;
   u32 *myc = cnt[w];  // this wave's counters: no other wave touches them before the barrier
   u32 dig[RS_ITEMS], rk[RS_ITEMS];
-  // A text pass that keeps only the digits keep_lo .. keep_hi-1 (a leaf shared by several GPUs): the others are neither
-  // ranked nor staged, the tile shrinks to what is kept (tile_kept).
+  // A text pass that keeps only the digits keep_lo .. keep_hi-1 (a leaf shared by several GPUs) and leaves out the
+  // elements whose bit in dropm is set (TextKeys::run_span): the others are neither ranked nor staged, the tile
+  // shrinks to what is kept (tile_kept).
   const bool filt = REVERSE && sizeof(K) == 8 && !HAS_VALS && !SIDE && keep_hi != 0;
   u32 keepm = ~0u, tile_kept = tile_n;
   if constexpr (ANY_ORDER) {
@@ -303,7 +326,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       dig[r] = digit_of<K>(key[r], shift, mask);
       rk[r] = 0;
       bool valid = FULL || wbase + r * 64 + lane < tile_n;
-      if (filt && (dig[r] < keep_lo || dig[r] >= keep_hi)) {
+      if (filt && (dig[r] < keep_lo || dig[r] >= keep_hi || ((dropm >> r) & 1u))) {
         valid = false;
         keepm &= ~(1u << r);
       }
@@ -471,6 +494,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
 
   K key[RS_ITEMS];
   u32 val[RS_ITEMS];
+  u32 dropm = 0;  // elements of the text pass that are left out (TextKeys::run_span)
   const u32 wbase = w * RS_PER_WAVE;
   if constexpr (TEXT) {
     // The same buffer first holds the staged text (behind the key exchange area) and the keys that
@@ -512,6 +536,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
         // (d1 = the key's top b1 bits, which this pass sorts on and does not store; d2 = the b2 bits below them)
         const u64 hi = (k << tk.b1) & (~0ull << (64 - tk.b2 - tk.lean_deep));
         const u32 d1 = (u32)(k >> (64 - tk.b1));
+        dropm |= (u32)tk_left_out(stage, idx, k, tk) << r;
         key[r] = (K)(hi | ((u64)((u32)k & 0xFFu) << tk.pbits) | (u64)(d1 << 13) | idx);
       } else {  // packed element: codes | preceding symbol | window index
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
@@ -566,11 +591,11 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u);
+                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u);
+                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -804,12 +829,19 @@ __global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride
   const u64 p = first + (t >> 4) * stride + (t & 15);
   const u32 ms = tk.min_sym - (u32)tk.one_based;
   u64 sf = 0;
+  const u32 cm = tk.code_max ? tk.code_max : 0xFFu;
+  u32 copies = 0;  // of the run symbol at the suffix's start
+  bool seen = false;  // code_max: a symbol that shares its code has gone by; the largest code from there on
   for (int k = 0; k < tk.K0; k++) {
     const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
-    if (tk.base) sf = sf * tk.base + (ch ? ch - ms : 0u);
-    else sf = (sf << tk.w) | (ch ? ch - ms : 0u);
+    const u32 code = seen ? cm : (ch ? min(ch - ms, cm) : 0u);
+    if (tk.base) sf = sf * tk.base + code;
+    else sf = (sf << tk.w) | code;
+    copies += (copies == (u32)k && ch == tk.run_sym);
+    seen = seen || (tk.code_max && ch == tk.run_sym);
   }
   const u64 key = tk.base ? (sf * tk.scale) << 8 : sf << (64 - tk.K0 * tk.w);
+  if (key - tk.run_lo < tk.run_span && copies >= tk.run_k) return;  // left out of the sort (run_span 0: never)
   atomicAdd(&per_bucket[(u32)(key >> (64 - bbits))], 1u);
 }
 
@@ -1125,7 +1157,8 @@ static void lean_text_scatter(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKe
   const u32 mask = (1u << tk.b1) - 1u;
   KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
   // the staged elements carry the digit above the low 13 bits of their position field
-  if (c.lean_any_order)
+  // (only the any-order ranking knows how to leave elements out)
+  if (c.lean_any_order || tk.keep_hi)
     hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, true, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                        (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
                        (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
@@ -1234,7 +1267,16 @@ void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 
   else gap_sort_lean_impl<8, 8>(c, keys, n, low, b1, b2, start);
 }
 
-int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard) {
+int lean_count_symbols(const TextKeys &text) {
+  const int bbits = text.b1 + text.b2;
+  // the text pass's histogram only needs the top bbits bits: 16 symbols keep its fast key roll
+  // (not with digits of another base: there every symbol of the key can reach the top bits)
+  if (!text.base && text.K0 * text.w > 32 && 32 / text.w * text.w >= bbits) return 32 / text.w;
+  return text.K0;
+}
+
+int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const TextKeys &text, BucketState *bs, LeanShard *shard,
+                        size_t *kept_out) {
   const int bbits = text.b1 + text.b2;
   if (!text.lean || text.b1 < 1 || text.b1 > 9 || text.b2 < 1 || text.b2 > 10 || text.pbits < 13 + text.b1 || text.pbits > 32 ||
       n >= (1ull << 32) - 8 || ((n - 1) >> text.pbits) || text.lean_deep < 16 || text.b1 + text.b2 + text.lean_deep > 48 ||
@@ -1247,9 +1289,8 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   const u32 nd1 = 1u << text.b1, n_buckets = 1u << bbits;
   TextKeys first = text;
   first.next_digits = nullptr;
-  TextKeys count_keys = first;  // the histogram only needs the top bbits bits: 16 symbols keep its fast key roll
-  // (not with digits of another base: there every symbol of the key can reach the top bits)
-  if (!text.base && count_keys.K0 * count_keys.w > 32 && 32 / count_keys.w * count_keys.w >= bbits) count_keys.K0 = 32 / count_keys.w;
+  TextKeys count_keys = first;
+  count_keys.K0 = lean_count_symbols(text);
   DBuf<u32> counts(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
   DBuf<u32> tfirst(c, nd1 + 1), rstart(c, nd1 + 1);
   if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
@@ -1295,7 +1336,24 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
     shard->bounds.assign(2, 0);
     shard->bounds[1] = n;
   }
-  scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, nullptr);
+  if (text.run_span) {
+    // suffixes left out of the sort: what is kept is what the histogram counted
+    if (shard && shard->parts > 1) fail(BWT_HIP_EINTERNAL, "leaf sort: a share of a leaf with suffixes left out");
+    first.keep_lo = 0;
+    first.keep_hi = dig1;
+    u32 *d_kept = c.d_scalars + 12;
+    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, d_kept);
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_kept, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    kept = c.h_scalars[0];
+    if (shard) {
+      shard->count = kept;
+      shard->bounds[1] = kept;
+    }
+  } else {
+    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, nullptr);
+  }
+  if (kept_out) *kept_out = kept;
   const size_t room = kept > 0 ? kept : 1;
   elems[0] = DBuf<u64>(c, room);
   elems[1] = DBuf<u64>(c, room);

@@ -581,8 +581,11 @@ constexpr u32 DF_DEPTH = 512;
 
 // is T[y:] < T[x:] ?  (x != y)  Positions at or past n read as the empty suffix, the smallest; of two
 // exhausted suffixes the shorter is the smaller (TextKeys, zero-based coding).  *decided = false when the
-// first DF_DEPTH symbols are equal.
-__device__ __forceinline__ bool text_less(const u8 *__restrict__ T, u64 n, u64 y, u64 x, bool *decided) {
+// first DF_DEPTH symbols are equal.  runs (may be null): the text's long periodic stretches (Ctx::runs); where both
+// suffixes have come to lie inside stretches of one period the comparison steps to the end of the shorter remainder,
+// which does not count as depth (two suffixes that begin just before long runs of one symbol).
+__device__ __forceinline__ bool text_less(const u8 *__restrict__ T, u64 n, u64 y, u64 x, bool *decided,
+                                          const u32 *__restrict__ runs = nullptr, u32 n_runs = 0) {
   *decided = true;
   u32 d = 0;
   while (d < DF_DEPTH) {
@@ -595,6 +598,16 @@ __device__ __forceinline__ bool text_less(const u8 *__restrict__ T, u64 n, u64 y
         return ((wy >> at) & 0xFFu) < ((wx >> at) & 0xFFu);
       }
       d += 8;
+      if (n_runs && (d & 63u) == 0) {
+        u64 ey = 0, ex = 0;
+        const u32 py = run_around(runs, n_runs, y + d, &ey);
+        const u32 px = py ? run_around(runs, n_runs, x + d, &ex) : 0u;
+        if (py && py == px) {
+          const u64 skip = ey - (y + d) < ex - (x + d) ? ey - (y + d) : ex - (x + d);
+          y += skip;
+          x += skip;
+        }
+      }
     } else {
       const bool ey = y + d >= n, ex = x + d >= n;
       if (ey || ex) return ey && (!ex || y > x);
@@ -640,6 +653,8 @@ struct EmitParams {
   u64 n, a, m;
   i64 ns;            // samples to take (already min(m, ssa_n_samples))
   u8 *L;             // may be null: suffix array only
+  const u32 *runs;   // the text's long periodic stretches for the comparisons to step over (may be null)
+  u32 n_runs;
   u64 *samp;         // slot y of the position-ordered samples: position << 32 | rank (one store per sample); ~0 = empty
   u32 *special;
 };
@@ -759,7 +774,7 @@ struct LeafEmit : EmitParams {
       bool decided = true, less;
       const u32 xj = w.extra(j);
       if (xj != xi) less = xj < xi;
-      else less = text_less(T, n, (u64)pj + h, (u64)pos + h, &decided);
+      else less = text_less(T, n, (u64)pj + h, (u64)pos + h, &decided, runs, n_runs);
       if (!decided) {
         *fail = 1;
         return;
@@ -1310,21 +1325,25 @@ constexpr u32 RP_SAMPLES = 1u << 18;
 constexpr u32 RP_TABLE = 1u << 20;
 
 __global__ void k_repeat_probe(const u8 *__restrict__ T, u64 n, u64 a, u64 N, u64 stride, unsigned long long *__restrict__ table,
-                               u32 *__restrict__ collisions) {
+                               u32 *__restrict__ collisions, int skip_runs) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= RP_SAMPLES) return;
   u64 x = (t + 1) * 0x9E3779B97F4A7C15ull;  // the position's place inside its stretch
   x ^= x >> 29;
   const u64 p = a + t * stride + (x % stride);
   if (p + 64 > n || p >= a + N) return;
-  u64 h = 0xCBF29CE484222325ull;
+  u64 h = 0xCBF29CE484222325ull, first = 0;
+  bool one_symbol = true;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     u64 w;
     __builtin_memcpy(&w, T + p + 8 * k, 8);
+    if (k == 0) first = w;
+    one_symbol = one_symbol && w == first && w == (w & 0xFFu) * 0x0101010101010101ull;
     h = (h ^ w) * 0x100000001B3ull;
     h ^= h >> 32;
   }
+  if (skip_runs && one_symbol) return;  // inside a run of one symbol: those are dealt with apart (RunPlan)
   h |= 1ull;  // 0 marks an empty slot
   u32 slot = (u32)(h >> 40) & (RP_TABLE - 1);
   for (u32 probes = 0; probes < RP_TABLE; probes++) {
@@ -1338,7 +1357,7 @@ __global__ void k_repeat_probe(const u8 *__restrict__ T, u64 n, u64 a, u64 N, u6
   }
 }
 
-static bool window_has_long_repeats(Ctx &c, i64 a, u64 N) {
+static bool window_has_long_repeats(Ctx &c, i64 a, u64 N, bool skip_runs) {
   if (N < c.bucket_min_n || N < (u64)RP_SAMPLES * 64 || !c.repeat_probe) return false;
   KernelTimer kt(c, "leaf:k_repeat_probe", (double)RP_SAMPLES * 64);
   DBuf<unsigned long long> table(c, RP_TABLE);
@@ -1346,7 +1365,7 @@ static bool window_has_long_repeats(Ctx &c, i64 a, u64 N) {
   HIP_CHECK(hipMemsetAsync(table.get(), 0, (size_t)RP_TABLE * 8, c.stream));
   HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
   hipLaunchKernelGGL(k_repeat_probe, dim3(RP_SAMPLES / 256), dim3(256), 0, c.stream, c.T, (u64)c.n, (u64)a, N, N / RP_SAMPLES,
-                     table.get(), d_count);
+                     table.get(), d_count, skip_runs ? 1 : 0);
   HIP_CHECK(hipGetLastError());
   return read_u32(c, d_count) >= 8;
 }
@@ -2286,14 +2305,306 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   return 1;
 }
 
+// ----------------------------------------------------------------------------
+// Long runs of one symbol (the N of an assembly's gaps: millions of symbols) in closed form.  The suffixes that begin
+// with kf copies of the run symbol c share one key; there are as many of them as the runs are long, far more than a
+// bucket holds, and prefix doubling keeps a run of R symbols tied for log2 R rounds.  But their order is known:
+// such a suffix is c^m X with X not beginning with c, and of two of them with m < m' the first is the smaller one
+// exactly when X begins with a symbol below c -- so those whose run is followed by a smaller symbol come first, in
+// the order of m, then those followed by a larger one, in the opposite order of m; equal m are decided by X.  The lean
+// route leaves these suffixes out of its sort (TextKeys::run_span), ranks them with one radix sort on
+// (follower below or above c, m or -m, the first symbols of X) plus text comparisons of the few that still agree, and
+// inserts them as one block of consecutive ranks where their key falls among the others.
+// ----------------------------------------------------------------------------
+struct RunPlan {
+  bool on = false;
+  u32 sym = 0;  // the symbol whose runs are taken out
+  // The symbol is the alphabet's largest and rare outside its runs (the N of an assembly, coded behind the bases): the
+  // keys then give it the code of the symbol below it (TextKeys::code_max) and use the key space of the alphabet
+  // without it -- with a code of its own that hardly ever occurs, a fifth symbol leaves four fifths of the key space
+  // empty at every digit, and the buckets that are used overflow.
+  bool merge = false;
+};
+
+// *out += the positions of [a, b) that hold sym
+__global__ void __launch_bounds__(256) k_count_symbol(const u8 *__restrict__ T, u64 a, u64 b, u32 sym, u32 *__restrict__ out) {
+  u32 mine = 0;
+  for (u64 p = a + ((u64)blockIdx.x * 256 + threadIdx.x) * 8; p < b; p += (u64)gridDim.x * 256 * 8) {
+    if (p + 8 <= b) {
+      u64 w;
+      __builtin_memcpy(&w, T + p, 8);
+      const u64 x = w ^ (0x0101010101010101ull * sym);
+      u64 t = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+      t = ~(t | x | 0x7F7F7F7F7F7F7F7Full);
+      mine += (u32)__popcll(t);
+    } else {
+      for (u64 q = p; q < b; q++) mine += T[q] == sym;
+    }
+  }
+  mine = wave_reduce_sum(mine);
+  if (lane_id() == 0 && mine) atomicAdd(out, mine);
+}
+
+// the listed runs of one symbol that meet [a, b): worth it from 4096 positions on; the symbol of the longest
+static RunPlan plan_run_filter(Ctx &c, i64 a, i64 b) {
+  RunPlan rp;
+  if (!c.run_filter || !c.chunks.empty()) return rp;  // (a text that is still arriving has not been scanned for runs)
+  ensure_run_table(c);
+  const size_t cnt = c.n_runs;
+  i64 best = 0;
+  for (size_t i = 0; i < cnt; i++) {
+    if (c.runs_host[2 * cnt + i] != 1) continue;
+    const i64 s0 = c.runs_host[i], e0 = c.runs_host[cnt + i];
+    const i64 lo = s0 > a ? s0 : a, hi = e0 < b ? e0 : b;
+    if (hi - lo > best) {
+      best = hi - lo;
+      rp.sym = c.runs_host[3 * cnt + i];
+    }
+  }
+  rp.on = best >= 4096 && rp.sym != 0;
+  if (rp.on && (int)rp.sym == c.max_sym && c.max_sym > c.min_sym + 1 && c.min_sym > 0) {
+    i64 covered = 0;  // by the listed runs of this symbol
+    for (size_t i = 0; i < cnt; i++) {
+      if (c.runs_host[2 * cnt + i] != 1 || c.runs_host[3 * cnt + i] != rp.sym) continue;
+      const i64 s0 = c.runs_host[i], e0 = c.runs_host[cnt + i];
+      const i64 lo = s0 > a ? s0 : a, hi = e0 < b ? e0 : b;
+      if (hi > lo) covered += hi - lo;
+    }
+    u32 *d_count = c.d_scalars + 13;
+    HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_count_symbol, dim3(1024), dim3(256), 0, c.stream, c.T, (u64)a, (u64)b, rp.sym, d_count);
+    HIP_CHECK(hipGetLastError());
+    const i64 outside = (i64)read_u32(c, d_count) - covered;
+    rp.merge = outside * 512 < b - a;
+  }
+  return rp;
+}
+
+struct RunMatch {
+  const u8 *T;
+  u64 n;
+  u32 sym;
+  // bit k (k < count <= 64): position p0 + k holds the symbol
+  __device__ __forceinline__ u64 bits(u64 p0, int count) const {
+    u64 out = 0;
+    for (int k = 0; k < count; k += 8) {
+      u64 eight;
+      if (p0 + k + 9 <= n) {  // eight positions before the terminator
+        u64 w;
+        __builtin_memcpy(&w, T + p0 + k, 8);
+        const u64 x = w ^ (0x0101010101010101ull * sym);
+        u64 t = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+        t = ~(t | x | 0x7F7F7F7F7F7F7F7Full);                    // 0x80 in every byte that matched
+        eight = ((t >> 7) * 0x0102040810204080ull) >> 56;        // those eight bits, first position lowest
+      } else {
+        eight = 0;
+        for (int j = 0; j < 8; j++) {
+          const u64 p = p0 + k + j;
+          eight |= (u64)(p + 1 < n && T[p] == sym) << j;
+        }
+      }
+      out |= eight << k;
+    }
+    return count < 64 ? out & ((1ull << count) - 1ull) : out;
+  }
+  // of the 16 positions from p0 on (those below `end`): which begin kf copies of the symbol
+  __device__ __forceinline__ u32 left_out16(u64 p0, u64 end, int kf) const {
+    u64 r = bits(p0, 16 + kf - 1);
+    for (int len = 1; len < kf;) {
+      const int sft = len < kf - len ? len : kf - len;
+      r &= r >> sft;
+      len += sft;
+    }
+    u32 f = (u32)r & 0xFFFFu;
+    if (p0 + 16 > end) f &= (1u << (end - p0)) - 1u;
+    return f;
+  }
+};
+
+struct RunCountIn {
+  RunMatch rm;
+  u64 a, b;
+  int kf;
+  __device__ __forceinline__ u32 operator()(size_t i) const { return __popc(rm.left_out16(a + 16 * (u64)i, b, kf)); }
+};
+struct RunListOut {
+  RunMatch rm;
+  u64 a, b;
+  int kf;
+  u32 *P, cap;
+  u32 *total;
+  size_t n;
+  __device__ __forceinline__ void operator()(size_t i, u32 excl, u32 incl) const {
+    u32 f = rm.left_out16(a + 16 * (u64)i, b, kf);
+    u32 o = excl;
+    while (f) {
+      const u32 k = (u32)__ffs(f) - 1u;
+      if (o < cap) P[o] = (u32)(a + 16 * (u64)i + k);
+      o++;
+      f &= f - 1u;
+    }
+    if (i + 1 == n) *total = incl;
+  }
+};
+
+// *ext = how many positions from x0 on hold the symbol (x0 < n).  One workgroup: 2048 positions a step, and after every
+// step that found nothing else a look at the list of long runs, which says where the one around the position ends.
+__global__ void __launch_bounds__(256) k_run_ext(RunMatch rm, u64 x0, const u32 *__restrict__ runs, u32 n_runs, u32 *__restrict__ ext) {
+  __shared__ u32 first_s;
+  u64 p = x0;
+  for (;;) {
+    if (threadIdx.x == 0) first_s = 2048;
+    __syncthreads();
+    const u64 mine = p + 8 * threadIdx.x;
+    u64 m8 = 0;
+    for (int j = 0; j < 8; j++) m8 |= (u64)(mine + j + 1 < rm.n && rm.T[mine + j] == rm.sym) << j;
+    if (m8 != 0xFF) atomicMin(&first_s, 8 * threadIdx.x + (u32)__ffsll((unsigned long long)~m8) - 1u);
+    __syncthreads();
+    const u32 first = first_s;
+    __syncthreads();
+    if (first < 2048) {
+      if (threadIdx.x == 0) *ext = (u32)(p + first - x0);
+      return;
+    }
+    p += 2048;
+    u64 end = 0;
+    if (n_runs && run_around(runs, n_runs, p, &end) == 1 && end > p + 16) p = end - 8;
+  }
+}
+
+struct LastSetU32 {
+  __device__ __forceinline__ static u32 identity() { return 0; }
+  __device__ __forceinline__ static u32 apply(u32 earlier, u32 later) { return later ? later : earlier; }
+};
+// the list from its end: where a stretch of consecutive positions ends, that position + 1
+struct RunEndIn {
+  const u32 *P;
+  u32 cnt;
+  __device__ __forceinline__ u32 operator()(size_t j) const {
+    const u32 i = cnt - 1u - (u32)j;
+    return (i + 1 == cnt || P[i + 1] != P[i] + 1u) ? P[i] + 1u : 0u;
+  }
+};
+// key of list entry i: | follower above c, 1 bit | m, or 2^32 - 1 - m behind a larger follower, 32 bits | codes of the
+// first kx symbols behind the run, 31 bits |
+struct RunKeyOut {
+  const u32 *P;
+  u32 cnt;
+  const u8 *T;
+  u64 n, b;
+  u32 kf, sym, min_sym;
+  const u32 *ext;
+  int wx, kx;
+  u64 *keys;
+  u32 *vals;
+  __device__ __forceinline__ void operator()(size_t j, u32, u32 incl) const {
+    const u32 i = cnt - 1u - (u32)j;
+    const u64 q = P[i], last = (u64)incl - 1u;  // the stretch's last position that begins kf copies
+    u64 m = last + kf - q;
+    if (last + 1 == b) m += *ext;               // the run goes on behind the leaf
+    const u64 x = q + m;
+    const u32 f = x < n ? T[x] : 0u;
+    const u64 above = f > sym;
+    const u64 mm = above ? 0xFFFFFFFFull - m : m;
+    u64 xp = 0;
+    for (int k = 0; k < kx; k++) {
+      const u32 ch = x + k < n ? T[x + k] : 0u;
+      xp = (xp << wx) | (ch ? ch - min_sym + 1u : 0u);
+    }
+    xp <<= 31 - kx * wx;
+    keys[i] = (above << 63) | (mm << 31) | xp;
+    vals[i] = (u32)q;
+  }
+};
+
+// *out = leaf rank of the block: the sorted suffixes whose key lies below the keys left out.  They sit in one
+// bucket (bkt) and before it; an element shows the key's bits below the first digit down to a precision that may
+// be coarser than the key, so an element inside the range those bits leave open is compared on the text.
+__global__ void __launch_bounds__(256) k_run_block_start(const u64 *__restrict__ el, const u32 *__restrict__ start, u32 bkt, TextKeys tk,
+                                                         u32 posmask, u32 sym, u32 kf, u32 *__restrict__ out) {
+  __shared__ u32 scan_s[17];
+  const u32 s0 = start[bkt], s1 = start[bkt + 1];
+  const u64 topmask = ~0ull << (64 - tk.b2 - tk.lean_deep);
+  const u64 t_lo = (tk.run_lo << tk.b1) & topmask, t_hi = ((tk.run_lo + (tk.run_span - 256)) << tk.b1) & topmask;
+  u32 below = 0;
+  for (u32 i = s0 + threadIdx.x; i < s1; i += 256) {
+    const u64 e = el[i], t = e & topmask;
+    if (t < t_lo) {
+      below++;
+    } else if (t <= t_hi) {
+      const u64 p = tk.a + ((u32)e & posmask);
+      for (u32 j = 0; j < kf; j++) {  // (it does not begin with kf copies of the symbol: it would have been left out)
+        const u32 ch = p + j < tk.n ? tk.T[p + j] : 0u;
+        if (ch != sym) {
+          below += ch < sym;
+          break;
+        }
+      }
+    }
+  }
+  u32 tot;
+  block_scan_incl<OpSum>(below, scan_s, &tot);
+  if (threadIdx.x == 0) *out = s0 + tot;
+}
+
+// the sorted suffixes' samples and special ranks, written with ranks that do not count the block: those behind it move up
+__global__ void k_run_shift_samples(u64 *__restrict__ samp, i64 ns, u32 *__restrict__ special, const u32 *__restrict__ at, u32 cnt) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 B = *at;
+  if (i < 2 && special && special[i] >= B) special[i] += cnt;
+  if ((i64)i >= ns || !samp) return;
+  const u64 v = samp[i];
+  if (v != ~0ull && (u32)v >= B) samp[i] = v + cnt;
+}
+
+// Entry i of the block (sorted on RunKeyOut's keys) takes rank *at + i, or, where keys agree, the rank that the text
+// behind the run and the key's symbols gives it among those.
+template <class View>
+__global__ void k_run_place(LeafEmit<View> E, const u64 *__restrict__ keys, const u32 *__restrict__ pos, u32 cnt,
+                            const u32 *__restrict__ at, int kx) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const u64 key = keys[i];
+  u32 rank = i;
+  if ((i > 0 && keys[i - 1] == key) || (i + 1 < cnt && keys[i + 1] == key)) {
+    u32 gs = i, ge = i;
+    while (gs > 0 && i - gs < DF_GROUP && keys[gs - 1] == key) gs--;
+    while (ge + 1 < cnt && ge - i < DF_GROUP && keys[ge + 1] == key) ge++;
+    if (i - gs >= DF_GROUP || ge - i >= DF_GROUP) {
+      *E.fail = 1;
+      return;
+    }
+    const u64 mm = (key >> 31) & 0xFFFFFFFFull;
+    const u64 depth = ((key >> 63) ? 0xFFFFFFFFull - mm : mm) + (u64)kx;
+    u32 smaller = 0;
+    for (u32 j = gs; j <= ge; j++) {
+      if (j == i) continue;
+      bool decided;
+      const bool less = text_less(E.T, E.n, (u64)pos[j] + depth, (u64)pos[i] + depth, &decided, E.runs, E.n_runs);
+      if (!decided) {
+        *E.fail = 1;
+        return;
+      }
+      smaller += less;
+    }
+    rank = gs + smaller;
+  }
+  E.place((u64)*at + rank, pos[i], E.sym_before(pos[i]));
+}
+
 // Lean bucket route: windows of up to 2^32 - 9 suffixes of small symbols (DNA), 8-byte elements with nothing on the
 // side (TextKeys::lean).  Two radix passes -- the text pass on the lower b1 bucket bits, which it does not store,
 // the second on the top b2 -- leave 2^(b1+b2) buckets of a few thousand suffixes; k_bucket_emit orders a bucket in
 // LDS on the next 16 key bits, settles what those leave tied on the key bits below them and only then on the
 // text.  1: done.  0: not applicable or given up (skewed or repetitive text), nothing usable was written.
 static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int span, const EmitParams *E, DBuf<u32> *sa_out,
-                          LeanShard *shard = nullptr) {
+                          LeanShard *shard = nullptr, const RunPlan *rp = nullptr) {
   if (N < c.bucket_min_n || N < 2 || N >= (1ull << 32) - 8) return 0;
+  // a largest symbol that shares the code of the one below it (RunPlan::merge): the keys' alphabet is one smaller
+  // (only where the alphabet without it has 2^k symbols: bit-field codes)
+  const bool merged = rp && rp->on && rp->merge && !shard && e == b && span >= 2 && rp->sym == min_sym + (u32)span &&
+                      ((u32)span & (u32)(span - 1)) == 0;
+  if (merged) span--;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
   // Alphabets of 3, 5, 6 or 7 symbols (DNA with N): the codes as digits of a number in that base, scaled to the top of
   // 56 bits (TextKeys::base) -- bit fields would spend 2 or 3 bits on 1.6 to 2.8 bits of information and leave dozens
@@ -2331,8 +2642,9 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   if (deep < 16) return 0;
   const int K0 = base ? K0b : (bbits + deep + w - 1) / w;  // covers every stored key bit (K0 * w <= 56)
   const int h16 = (bbits + 16) / w;                        // symbols covered by the bits the buckets are ordered on
-  // whole symbols that two elements with the same key bits are known to share: none with digits of another base
-  const int h = base ? 0 : (bbits + deep) / w;
+  // whole symbols that two elements with the same key bits are known to share: none with digits of another base, or
+  // with two symbols behind one code
+  const int h = (base || merged) ? 0 : (bbits + deep) / w;
   const double sigma = span + 1 < 2 ? 2.0 : (double)(span + 1);
   if (base) {
     if ((double)N / (ldexp(1.0, bbits + 16) * fill) > 0.25) return 0;
@@ -2348,16 +2660,90 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   tk.base = base;
   tk.scale = scale;
   tk.lead = lead;
+  // long runs of one symbol: the suffixes that begin with kf copies of it stay out of the sort (RunPlan)
+  // How many copies, kf: few enough that a suffix with kf - 1 of them still shows some symbols of what follows the
+  // run in the 16 key bits its bucket is ordered on (the bucket kernel gives up on 16 equal values: one such suffix per
+  // run would do), enough that the keys left out fall inside one bucket.
+  bool runf = rp && rp->on && !shard && e == b && rp->sym >= min_sym && (int)(rp->sym - min_sym) <= span + (merged ? 1 : 0);
+  int kf = h16 > 7 ? h16 - 6 : 1;
+  if (merged) tk.code_max = (u32)(span + one_based);
+  if (runf) {
+    const u64 B = base ? base : 1ull << w, scl = base ? scale : 1ull << (56 - K0 * w);
+    u64 code_c = rp->sym - min_sym + (u32)one_based;
+    if (merged) code_c = tk.code_max;
+    const int kmax = lean_count_symbols(tk);  // what the counting pass sees of a key
+    // (a symbol without a code of its own: every suffix that begins with it is left out -- their keys are all the
+    // same -- and, the symbol being the largest, their block comes behind everything else)
+    if (merged) kf = 1;
+    for (runf = false; kf <= kmax && !runf; kf++) {
+      u64 lead_kf = 0, rest = 1;
+      for (int j = 0; j < kf; j++) lead_kf = lead_kf * B + code_c;
+      for (int j = kf; j < K0; j++) rest *= B;
+      tk.run_lo = (lead_kf * rest * scl) << 8;
+      tk.run_span = (rest * scl) << 8;
+      runf = merged || (tk.run_lo >> (64 - bbits)) == ((tk.run_lo + (tk.run_span - 256)) >> (64 - bbits));
+    }
+    kf--;
+    if (!runf) tk.run_lo = tk.run_span = 0;
+    tk.run_sym = rp->sym;
+    tk.run_k = (u32)kf;
+  }
+  if (merged && !runf) return 0;
   DBuf<u64> el[2];
   BucketState bs;
   int cur;
+  size_t kept = N;
   {
     Phase ph(c, "leaf_radix_sort", (double)N * (1 + 1 + 8 + 8 + 16));
-    cur = leaf_sort_text_lean(c, el, N, BK_CAP, tk, &bs, shard);
+    cur = leaf_sort_text_lean(c, el, N, BK_CAP, tk, &bs, shard, &kept);
   }
   if (cur < 0) return 0;
   const u32 n_buckets = 1u << bbits;
   u32 *d_fail = c.d_scalars + 10;
+  // the block of suffixes left out: listed, keyed and sorted while the others wait for their bucket kernel
+  const u32 run_cnt = (u32)(N - kept);
+  u32 *d_run_at = c.d_scalars + 32, *d_run_ext = c.d_scalars + 33;
+  DBuf<u64> rk0, rk1;
+  DBuf<u32> rv0, rv1;
+  int rcur = 0;
+  const int wx = bits_for((u64)span + 1), kx = 31 / wx;
+  if (runf && run_cnt > 0) {
+    Phase ph(c, "leaf_run_block", (double)N + (double)run_cnt * 8 * 24);
+    u32 *d_total = c.d_scalars + 8;
+    const RunMatch rm{c.T, (u64)c.n, rp->sym};
+    DBuf<u32> P(c, run_cnt);
+    const size_t chunks = (size_t)((N + 15) / 16);
+    scan_generic<u32, SumU32>(c, chunks, RunCountIn{rm, (u64)a, (u64)b, kf},
+                              RunListOut{rm, (u64)a, (u64)b, kf, P.get(), run_cnt, d_total, chunks});
+    if (read_u32(c, d_total) != run_cnt)
+      fail(BWT_HIP_EINTERNAL, "leaf sort: %u suffixes left out of the sort, %u begin with %d copies of symbol %u", run_cnt,
+           c.h_scalars[0], kf, rp->sym);
+    HIP_CHECK(hipMemsetAsync(d_run_ext, 0, sizeof(u32), c.stream));
+    const u64 x0 = (u64)b - 1 + (u64)kf;
+    if (x0 < (u64)c.n) {
+      hipLaunchKernelGGL(k_run_ext, dim3(1), dim3(256), 0, c.stream, rm, x0, (const u32 *)c.runs, c.n_runs, d_run_ext);
+      HIP_CHECK(hipGetLastError());
+    }
+    rk0 = DBuf<u64>(c, run_cnt);
+    rk1 = DBuf<u64>(c, run_cnt);
+    rv0 = DBuf<u32>(c, run_cnt);
+    rv1 = DBuf<u32>(c, run_cnt);
+    scan_generic<u32, LastSetU32>(c, run_cnt, RunEndIn{P.get(), run_cnt},
+                                  RunKeyOut{P.get(), run_cnt, c.T, (u64)c.n, (u64)b, (u32)kf, rp->sym, min_sym, d_run_ext, wx, kx,
+                                            rk0.get(), rv0.get()});
+    u64 *keys[2] = {rk0.get(), rk1.get()};
+    u32 *vals[2] = {rv0.get(), rv1.get()};
+    c.sort_tag = "run:";
+    rcur = radix_sort_u64(c, keys, vals, run_cnt, 0, 64);
+    c.sort_tag = "";
+    if (merged) {
+      HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d_run_at, (int)(u32)kept, 1, c.stream));
+    } else {
+      hipLaunchKernelGGL(k_run_block_start, dim3(1), dim3(256), 0, c.stream, (const u64 *)el[cur].get(), (const u32 *)bs.start.get(),
+                         (u32)(tk.run_lo >> (64 - bbits)), tk, (u32)((1ull << pbits) - 1ull), rp->sym, (u32)kf, d_run_at);
+      HIP_CHECK(hipGetLastError());
+    }
+  }
   // A GPU that holds a share of the leaf (shard) has its elements, its stretch of L and of the suffix array at local
   // index = leaf rank - first_rank; the bucket bounds are leaf ranks, so the three arrays are addressed from where
   // rank 0 would lie.
@@ -2376,7 +2762,7 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   if (em.L) em.L -= first_rank;
   em.sa_out = sa_out ? res.get() - first_rank : nullptr;
   em.v = LeanView{el[cur].get() - first_rank, (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16};
-  em.N = N;
+  em.N = first_rank + kept;  // (ranks: a share's elements begin at its first rank)
   em.sym_mask = ~0xFFull;  // BucketWindow<LeanView>::key: the ordered key bits above the preceding symbol
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;
   em.h = (u64)h;
@@ -2384,6 +2770,10 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   em.fail = d_fail;
   em.T = c.T;
   em.n = (u64)c.n;
+  if (rp && rp->on) {  // (the list exists: RunPlan comes from it)
+    em.runs = c.runs;
+    em.n_runs = c.n_runs;
+  }
   HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
   {
     KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
@@ -2398,13 +2788,43 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
     }
   }
   if (read_u32(c, d_fail) != 0) return 0;
+  if (runf && run_cnt > 0) {
+    // the sorted suffixes behind the block move up by its length, then the block takes its ranks
+    Phase ph(c, "leaf_run_block", (double)kept * 2 + (double)run_cnt * 16);
+    const u32 at = read_u32(c, d_run_at);
+    if (at > kept) fail(BWT_HIP_EINTERNAL, "leaf sort: the block of run suffixes at rank %u of %zu", at, kept);
+    const size_t tail = kept - at;
+    if (tail > 0 && em.L) {
+      DBuf<u8> tmp(c, tail);
+      HIP_CHECK(hipMemcpyAsync(tmp.get(), em.L + at, tail, hipMemcpyDeviceToDevice, c.stream));
+      HIP_CHECK(hipMemcpyAsync(em.L + at + run_cnt, tmp.get(), tail, hipMemcpyDeviceToDevice, c.stream));
+      c.sync();  // tmp goes back to the pool
+    }
+    if (tail > 0 && em.sa_out) {
+      DBuf<u32> tmp(c, tail);
+      HIP_CHECK(hipMemcpyAsync(tmp.get(), em.sa_out + at, tail * sizeof(u32), hipMemcpyDeviceToDevice, c.stream));
+      HIP_CHECK(hipMemcpyAsync(em.sa_out + at + run_cnt, tmp.get(), tail * sizeof(u32), hipMemcpyDeviceToDevice, c.stream));
+      c.sync();
+    }
+    if (em.L) {
+      const u64 slots = em.ns > 2 ? (u64)em.ns : 2;
+      hipLaunchKernelGGL(k_run_shift_samples, dim3(ceil_div(slots, 256)), dim3(256), 0, c.stream, em.samp, em.ns, em.special,
+                         (const u32 *)d_run_at, run_cnt);
+      HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_run_place<LeanView>, dim3(ceil_div(run_cnt, 256)), dim3(256), 0, c.stream, em, (const u64 *)(rcur ? rk1.get() : rk0.get()),
+                       (const u32 *)(rcur ? rv1.get() : rv0.get()), run_cnt, (const u32 *)d_run_at, kx);
+    HIP_CHECK(hipGetLastError());
+    if (read_u32(c, d_fail) != 0) return 0;
+  }
   if (sa_out) *sa_out = std::move(res);
   return 1;
 }
 
 // Sorts the window [a,e).  On success: if E is not null the leaf's L, special ranks and samples have
 // been written through it; if sa_out is not null it holds the leaf suffix array (b-a entries).
-static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out, bool repeats, int dc_state, int *redo) {
+static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u32> *sa_out, bool repeats, int dc_state, int *redo,
+                        const RunPlan *rp = nullptr) {
   const u64 N = (u64)(e - a);
   const u32 min_sym = (u32)(c.min_sym > 0 ? c.min_sym : 1);
   const int span = c.max_sym > (int)min_sym ? c.max_sym - (int)min_sym : 0;
@@ -2420,7 +2840,7 @@ static bool sort_window(Ctx &c, i64 a, i64 b, i64 e, const EmitParams *E, DBuf<u
   // itself, so they sort the leaf's own suffixes and no window slack.  (force_wide 3: never the lean route; windows
   // the packed elements can index then take those elements' own bucket route, the lean route's predecessor.)
   const u64 NL = (u64)(b - a);
-  if (!repeats && c.force_wide != 1 && c.force_wide != 3 && try_lean_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1) return true;
+  if (!repeats && c.force_wide != 1 && c.force_wide != 3 && try_lean_route(c, a, b, b, NL, min_sym, span, E, sa_out, nullptr, rp) == 1) return true;
   if (!repeats && (!kp.pbits || c.force_wide == 1) && try_wide_route(c, a, b, b, NL, min_sym, span, E, sa_out) == 1) return true;
   if (kp.pbits) {
     // packed elements; the spare buffer later holds the first active list (2N words)
@@ -2491,14 +2911,15 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   // a large leaf is probed for long repeats: such a text skips the bucket routes and the direct pass, and, where the
   // sample ranks may be used, is sorted without slack from the start
   c.wait_text((u64)b + 128);
-  const bool repeats = window_has_long_repeats(c, a, (u64)(b - a));
+  const RunPlan rp = plan_run_filter(c, a, b);
+  const bool repeats = window_has_long_repeats(c, a, (u64)(b - a), rp.on);
   if (repeats && c.dc_mode > 0) dc_state = 1;
   for (;;) {
     const i64 e = dc_state == 1 ? b : b + slack;
     // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it
     c.wait_text((u64)e + DF_DEPTH + 128);
     int redo = 0;
-    if (sort_window(c, a, b, e, E, sa_out, repeats, dc_state, &redo)) return;
+    if (sort_window(c, a, b, e, E, sa_out, repeats, dc_state, &redo, &rp)) return;
     if (redo == REDO_DC) {
       dc_state = 1;
       continue;
@@ -2557,7 +2978,7 @@ bool build_leaf_share(Ctx &c, i64 a, i64 b, i64 ns_req, int part, int parts, Lea
   const i64 ns = ns_req < m ? ns_req : m;
   if (ns < 2) fail(BWT_HIP_EINVAL, "ssa_n_samples must be at least 2 (got %ld)", (long)ns_req);
   c.wait_text((u64)b + DF_DEPTH + 128);
-  if (window_has_long_repeats(c, a, (u64)m)) return false;
+  if (window_has_long_repeats(c, a, (u64)m, false)) return false;
   out.samp = DBuf<u64>(c, (size_t)ns);
   out.ns = ns;
   HIP_CHECK(hipMemsetAsync(out.samp.get(), 0xFF, (size_t)ns * 8, c.stream));

@@ -348,3 +348,40 @@ def test_n3_1e9_one_leaf_over_eight_ranks_by_key_range(ctx):
     assert used == 8 and (s_rank, e_rank) == info1
     assert h8(L) == f1
     assert len(r) == len(r1) and (r == r1).all() and (p == p1).all()
+
+
+def test_runs_of_a_fifth_symbol_n1e9(ctx):
+    """n = 1e9 of random DNA with 31 runs of a fifth symbol (1e4 to 3e7 symbols, one across the leaf boundary: the N of
+    an assembly's gaps): the suffixes that begin inside the runs are left out of the leaves' sort and ranked in
+    closed form (phase leaf_run_block), the keys use the four-letter key space.  Decoded back to the text on the
+    device, L[rank] = T[pos-1] at every sample, adjacent suffixes in increasing order by host comparison, and the
+    same L from four leaves."""
+    n, run = 1000000000, 30000000
+    rng = np.random.default_rng(5)
+    T = rng.integers(1, 5, size=n, dtype=np.uint8)
+    at = n // 2 - run // 3
+    T[at:at + run] = 5
+    for _ in range(30):
+        length = int(10 ** rng.uniform(4, np.log10(run)))
+        where = int(rng.integers(0, n - length - 1))
+        T[where:where + length] = 5
+    T[-1] = 0
+    ctx.set_text(T)
+    ctx.set_timing(2)
+    ctx.reset_timers()
+    blk = ctx.pmbwt(n // 2, 1000000)
+    blocks, emits = launches(ctx, "leaf_run_block"), launches(ctx, "leaf:k_bucket_emit")
+    ctx.set_timing(0)
+    assert blocks == 4 and emits == 2  # both leaves on the lean route, each with a block of run suffixes
+    assert blk.ibwt_mismatches() == 0
+    L = blk.L
+    r, p = blk.samples()
+    assert (np.bincount(L, minlength=6) == np.bincount(T, minlength=6)).all()
+    assert p[0] == 0 and p[-1] == n - 1 and (L[r] == T[p - 1]).all()
+    _adjacent_ranks_increase(blk, T, L)
+    fnv = h8(L)
+    blk.free()
+    b4 = ctx.pmbwt(n // 4, 1000000)
+    assert h8(b4.L) == fnv
+    b4.free()
+    ctx.trim()
