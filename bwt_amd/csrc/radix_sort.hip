@@ -82,14 +82,17 @@ __device__ __forceinline__ void tk_stage(u32 *S32, const TextKeys &tk, u64 tile0
 }
 
 // keys k0 .. k0+ITEMS-1 of the tile (k0 a multiple of 4), from the staged text
-template <int ITEMS>
+// RUNF: the text may hold a symbol without a code of its own (TextKeys::code_max); compiled apart, because the few
+// registers it takes cost the common case a quarter of its waves.
+template <int ITEMS, bool RUNF = false>
 __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &tk, u64 key_out[ITEMS]) {
   const int w = tk.w, K0 = tk.K0;
   const int used = K0 * w;  // <= 56
   const u64 maskall = (1ull << used) - 1;
   const int lsh = 64 - used;
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
-  const u32 cm = tk.code_max ? tk.code_max : 0xFFu;  // (TextKeys::code_max)
+  const u32 code_max = RUNF ? tk.code_max : 0u;
+  const u32 cm = code_max ? code_max : 0xFFu;  // (TextKeys::code_max)
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
   const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
   if (w == 2 && !tk.one_based && !tk.base && K0 + ITEMS <= 32) {
@@ -108,7 +111,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
         const u32 x = src[q];
         if (q < WORDS / 2 + 1) wds[q] = x;
         plain = plain && !((x - 0x01010101u) & ~x & 0x80808080u);
-        if (tk.code_max) {  // a symbol whose code is not c - min_sym: the byte loop
+        if (code_max) {  // a symbol whose code is not c - min_sym: the byte loop
           const u32 z = x ^ (tk.run_sym * 0x01010101u);
           plain = plain && !((z - 0x01010101u) & ~z & 0x80808080u);
         }
@@ -154,19 +157,19 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
     sf = (sf << w) | (ch ? min(ch - ms, cm) : 0u);
-    if (tk.code_max) shared |= (u64)(ch == tk.run_sym) << k;
+    if (code_max) shared |= (u64)(ch == tk.run_sym) << k;
     wd >>= 8;
   }
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     u64 field = sf;
-    if (tk.code_max && shared) field |= (1ull << (used - w * (__builtin_ctzll(shared) + 1))) - 1ull;
+    if (code_max && shared) field |= (1ull << (used - w * (__builtin_ctzll(shared) + 1))) - 1ull;
     key_out[j] = (field << lsh) | raw[j - 1];  // the preceding symbol as it is
     const int k = K0 + j;
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
     sf = ((sf << w) | (ch ? min(ch - ms, cm) : 0u)) & maskall;
-    if (tk.code_max) shared = (shared >> 1) | ((u64)(ch == tk.run_sym) << (K0 - 1));
+    if (code_max) shared = (shared >> 1) | ((u64)(ch == tk.run_sym) << (K0 - 1));
     wd >>= 8;
   }
 }
@@ -183,7 +186,7 @@ __device__ __forceinline__ bool tk_left_out(const u32 *S32, u32 idx, u64 key, co
 // USE only names the caller in the kernel symbol (0 leaf sort, 1 refinement
 // rounds, 2 gap histogram), so that a profiler lists their launches apart.
 // DB: digit bits (8; 9 where two wider passes replace three; 10 for the second pass of lean windows above 2^31 suffixes)
-template <class K, int USE, bool TEXT, int DB = 8>
+template <class K, int USE, bool TEXT, int DB = 8, bool RUNF = false>
 __global__ void __launch_bounds__(RH_THREADS)
     k_rs_hist(const K *__restrict__ keys, size_t n, int shift, u32 mask, u32 *__restrict__ counts, u32 nblk,
               TextKeys tk, const uint2 *__restrict__ tmap = nullptr) {
@@ -199,11 +202,13 @@ __global__ void __launch_bounds__(RH_THREADS)
     tk_stage(stage, tk, tile0, tid, RH_THREADS);
     __syncthreads();
     u64 key[RH_ITEMS];
-    tk_roll<RH_ITEMS>(stage, tid * RH_ITEMS, tk, key);
+    tk_roll<RH_ITEMS, RUNF>(stage, tid * RH_ITEMS, tk, key);
 #pragma unroll
     for (int r = 0; r < RH_ITEMS; r++) {
       u32 d = (u32)(key[r] >> shift) & mask;
-      if (tile0 + tid * RH_ITEMS + r < n && !tk_left_out(stage, tid * RH_ITEMS + r, key[r], tk)) atomicAdd(&cnt[w][d], 1u);
+      bool counts = tile0 + tid * RH_ITEMS + r < n;
+      if constexpr (RUNF) counts = counts && !tk_left_out(stage, tid * RH_ITEMS + r, key[r], tk);
+      if (counts) atomicAdd(&cnt[w][d], 1u);
     }
     __syncthreads();
     for (u32 d = tid; d < (u32)DIG; d += RH_THREADS) {
@@ -455,7 +460,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
 // words), so that a histogram pass reads only the half that holds its digit.
 // SIDE: 8-byte keys-only elements with a side byte each (the wide layout of the leaf sort, TextKeys::wide):
 // side_in[i] belongs to kin[i] and moves with it to side_out.  The text pass makes both from the text.
-template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false, bool SIDE = false, int DB = 8>
+template <class K, bool HAS_VALS, int USE, bool TEXT, bool SPLIT, bool ANY_ORDER = false, bool SIDE = false, int DB = 8, bool RUNF = false>
 __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 : 8)
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     tk_stage(stage, tk, tile0, tid, RS_THREADS);
     __syncthreads();
     u64 mine[RS_ITEMS];
-    tk_roll<RS_ITEMS>(stage, tid * RS_ITEMS, tk, mine);
+    tk_roll<RS_ITEMS, RUNF>(stage, tid * RS_ITEMS, tk, mine);
     // Where the order inside a digit is free (ANY_ORDER) a thread ranks the keys it rolled itself: no exchange.
     // (Only whole tiles: the ranking's bookkeeping of a short tile assumes the slots of the exchange.)
     const bool direct = ANY_ORDER && full;
@@ -536,7 +541,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
         // (d1 = the key's top b1 bits, which this pass sorts on and does not store; d2 = the b2 bits below them)
         const u64 hi = (k << tk.b1) & (~0ull << (64 - tk.b2 - tk.lean_deep));
         const u32 d1 = (u32)(k >> (64 - tk.b1));
-        dropm |= (u32)tk_left_out(stage, idx, k, tk) << r;
+        if constexpr (RUNF) dropm |= (u32)tk_left_out(stage, idx, k, tk) << r;
         key[r] = (K)(hi | ((u64)((u32)k & 0xFFu) << tk.pbits) | (u64)(d1 << 13) | idx);
       } else {  // packed element: codes | preceding symbol | window index
         key[r] = (K)((k & 0xFFFFFFFF00000000ull) | (((u32)k & 0xFFu) << tk.pbits) | (u32)(tile0 + idx));
@@ -1147,8 +1152,12 @@ static void lean_text_hist(Ctx &c, size_t n, u32 nblk, const TextKeys &tk, const
   const int shift = 64 - tk.b1;
   const u32 mask = (1u << tk.b1) - 1u;
   KernelTimer kt(c, "leaf:k_rs_hist_text", (double)n);
-  hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
-                     mask, counts, nblk, count_keys, (const uint2 *)nullptr);
+  if (tk.run_span)
+    hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB, true>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
+                       mask, counts, nblk, count_keys, (const uint2 *)nullptr);
+  else
+    hipLaunchKernelGGL((k_rs_hist<u64, 0, true, DB>), dim3(nblk), dim3(RH_THREADS), 0, c.stream, (const u64 *)nullptr, n, shift,
+                       mask, counts, nblk, count_keys, (const uint2 *)nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1158,7 +1167,11 @@ static void lean_text_scatter(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKe
   KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
   // the staged elements carry the digit above the low 13 bits of their position field
   // (only the any-order ranking knows how to leave elements out)
-  if (c.lean_any_order || tk.keep_hi)
+  if (tk.run_span)
+    hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, true, false, DB, true>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                       (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
+                       (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
+  else if (c.lean_any_order || tk.keep_hi)
     hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, true, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
                        (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, counts, nblk, tk, 0u,
                        (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr);
