@@ -57,40 +57,65 @@ __device__ __forceinline__ u32 wave_count_below(const u32 *__restrict__ S, u32 m
   }
 }
 
-// aligned 16-byte loads of src[first : first + count) into LDS; returns where src[first] sits in `dst`
-__device__ __forceinline__ u32 stage_bytes(u8 *dst, const u8 *__restrict__ src, u64 first, u32 count, u32 tid) {
-  const uintptr_t ad = reinterpret_cast<uintptr_t>(src + first);
-  const u32 off = (u32)(ad & 15);
-  if (count == 0) return off;
-  const uint4 *base = reinterpret_cast<const uint4 *>(ad - off);
-  const u32 words = (off + count + 15) / 16;  // <= MG_CHUNK / 16 + 1
-  for (u32 q = tid; q < words; q += MG_THREADS) reinterpret_cast<uint4 *>(dst)[q] = base[q];
-  return off;
+// bounds[k] = number of left symbols placed before output position k * MG_CHUNK (k = 0 .. chunks): one wavefront
+// per boundary, so that the merge kernel's workgroups start with their stretch of S known instead of each searching
+// for both of its ends (three dependent rounds of loads at the head of every workgroup).
+__global__ void __launch_bounds__(256) k_merge_bounds(const u32 *__restrict__ S, u32 m, u64 total, float left_share, u32 chunks,
+                                                      u32 *__restrict__ bounds) {
+  const u32 k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k > chunks) return;
+  const u64 P = (u64)k * MG_CHUNK < total ? (u64)k * MG_CHUNK : total;
+  const u32 v = wave_count_below(S, m, P, left_share);
+  if (lane_id() == 0) bounds[k] = v;
 }
 
 __global__ void __launch_bounds__(MG_THREADS)
-    k_merge(const u8 *__restrict__ lL, const u8 *__restrict__ rL, const u32 *__restrict__ S, u32 m, u64 total,
-            float left_share, u8 *__restrict__ out) {
+    k_merge(const u8 *__restrict__ lL, const u8 *__restrict__ rL, const u32 *__restrict__ S, u64 total,
+            const u32 *__restrict__ bounds, u8 *__restrict__ out) {
   __shared__ u8 is_left[MG_CHUNK];
   __shared__ __align__(16) u8 src_l[MG_CHUNK + 32], src_r[MG_CHUNK + 32];  // the chunk's left and right symbols
-  __shared__ u32 bounds[2];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
-  const u64 p0 = (u64)blockIdx.x * MG_CHUNK;
+  // every XCD takes a contiguous range of chunks: the sectors that neighbouring chunks share then meet in one L2
+  const u32 chunk = xcd_tile(blockIdx.x, gridDim.x);
+  const u64 p0 = (u64)chunk * MG_CHUNK;
   const u64 p1 = (p0 + MG_CHUNK < total) ? p0 + MG_CHUNK : total;
+  const u32 tlo = bounds[chunk], thi = bounds[chunk + 1];
   reinterpret_cast<uint4 *>(is_left)[tid] = make_uint4(0, 0, 0, 0);
-  if (tid < 128) {  // waves 0 and 1: left symbols placed before p0, before p1
-    u32 v = wave_count_below(S, m, (tid < 64) ? p0 : p1, left_share);
-    if ((tid & 63) == 0) bounds[tid >> 6] = v;
-  }
-  __syncthreads();
-  const u32 tlo = bounds[0], thi = bounds[1];
-  for (u32 t = tlo + tid; t < thi; t += MG_THREADS) is_left[(u64)t + S[t] - p0] = 1;
-  // An aligned 16-byte block never straddles a page, so reading the whole block of a valid byte is safe.
   const u32 n_left = thi - tlo, n_right = (u32)(p1 - p0) - n_left;
   const u64 r0 = p0 - tlo;  // right symbols placed before p0
-  const u32 off_l = stage_bytes(src_l, lL, tlo, n_left, tid);
-  const u32 off_r = stage_bytes(src_r, rL, r0, n_right, tid);
+  // All loads of the chunk are issued before anything waits for one of them: its stretch of S (at most MG_PER_THREAD
+  // words a thread), its left and its right symbols (aligned 16-byte pieces, at most two a thread each; an aligned
+  // 16-byte block never straddles a page, so reading the whole block of a valid byte is safe).
+  const uintptr_t al = reinterpret_cast<uintptr_t>(lL + tlo), ar = reinterpret_cast<uintptr_t>(rL + r0);
+  const u32 off_l = (u32)(al & 15), off_r = (u32)(ar & 15);
+  const uint4 *bl = reinterpret_cast<const uint4 *>(al - off_l), *br = reinterpret_cast<const uint4 *>(ar - off_r);
+  const u32 wl = n_left ? (off_l + n_left + 15) / 16 : 0u, wr = n_right ? (off_r + n_right + 15) / 16 : 0u;  // <= MG_THREADS + 1
+  u32 sv[MG_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < MG_PER_THREAD; k++) {
+    const u32 t = tlo + (u32)k * MG_THREADS + tid;
+    sv[k] = t < thi ? S[t] : 0u;
+  }
+  uint4 vl[2], vr[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const u32 q = (u32)k * MG_THREADS + tid;
+    vl[k] = q < wl ? bl[q] : make_uint4(0, 0, 0, 0);
+    vr[k] = q < wr ? br[q] : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();  // the flags are cleared
+#pragma unroll
+  for (int k = 0; k < MG_PER_THREAD; k++) {
+    const u32 t = tlo + (u32)k * MG_THREADS + tid;
+    if (t < thi) is_left[(u64)t + sv[k] - p0] = 1;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const u32 q = (u32)k * MG_THREADS + tid;
+    if (q < wl) reinterpret_cast<uint4 *>(src_l)[q] = vl[k];
+    if (q < wr) reinterpret_cast<uint4 *>(src_r)[q] = vr[k];
+  }
   __syncthreads();
   const u32 q0 = tid * MG_PER_THREAD;
   uint4 fl = reinterpret_cast<const uint4 *>(is_left)[tid];
@@ -165,8 +190,11 @@ void merge_symbols(Ctx &c, const u8 *lL, u64 m, const u8 *rL, u64 rn, const u32 
   const u64 total = m + rn;
   if (total == 0) return;
   Phase ph(c, "merge_scatter", (double)total * 2 + (double)(m + 1) * 4);
-  hipLaunchKernelGGL(k_merge, dim3(ceil_div(total, MG_CHUNK)), dim3(MG_THREADS), 0, c.stream, lL, rL, S, (u32)m, total,
-                     (float)((double)m / (double)total), out);
+  const u32 chunks = ceil_div(total, MG_CHUNK);
+  DBuf<u32> bounds(c, (size_t)chunks + 1);
+  hipLaunchKernelGGL(k_merge_bounds, dim3(chunks / 4 + 1), dim3(256), 0, c.stream, S, (u32)m, total, (float)((double)m / (double)total),
+                     chunks, bounds.get());
+  hipLaunchKernelGGL(k_merge, dim3(chunks), dim3(MG_THREADS), 0, c.stream, lL, rL, S, total, (const u32 *)bounds.get(), out);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -35,15 +35,6 @@ constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES; // 512 consecutive keys per wave
 constexpr int RH_THREADS = 512;                 // histogram kernel: 512 threads x 16 keys
 constexpr int RH_ITEMS = RS_TILE / RH_THREADS;
 
-// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  This
-// bijection gives every XCD one contiguous range of tiles, so that the runs that
-// neighbouring tiles append to the same digit's output region meet in one L2
-// and leave it as whole lines.  Speed only: any mapping is correct (measured on
-// the 5e8-suffix leaf sort: scatter pass 2.39 ms with the mapping, 2.90 ms without).
-__device__ __forceinline__ u32 xcd_tile(u32 b, u32 nblk) {
-  u32 q = nblk >> 3, r = nblk & 7, x = b & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
 
 
 // ----------------------------------------------------------------------------
