@@ -1014,13 +1014,15 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
 // Cuts every region into tiles of RS_TILE elements (the last one shorter): tfirst[d] = number of tiles in the
 // regions below d (nd1 + 1 entries), tmap[t] = (first element, elements) of tile t; the tiles from tfirst[nd1] on
 // are empty (the caller's nblk2 is an upper bound that leaves at least one of them).
+// keep_lo, keep_hi: only the rows of these digits were scanned (a share of a leaf): the regions below are empty at 0,
+// those from keep_hi on empty at n.
 __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ offs1, u32 nblk, u32 nd1, u32 n,
                                                      u32 *__restrict__ tfirst, uint2 *__restrict__ tmap, u32 nblk2,
-                                                     u32 *__restrict__ rstart = nullptr) {
+                                                     u32 *__restrict__ rstart = nullptr, u32 keep_lo = 0, u32 keep_hi = ~0u) {
   __shared__ u32 rs[513], tf[513];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
-  if (tid < nd1) rs[tid] = offs1[(size_t)tid * nblk];
+  if (tid < nd1) rs[tid] = tid < keep_lo ? 0u : (tid >= keep_hi ? n : offs1[(size_t)tid * nblk]);
   if (tid == nd1) rs[tid] = n;
   __syncthreads();
   const u32 nt = tid < nd1 ? (rs[tid + 1] - rs[tid] + RS_TILE - 1) / RS_TILE : 0u;
@@ -1302,6 +1304,7 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   const u32 dig1 = text.b1 > 8 ? 512u : 256u;  // counter rows of the text pass
   size_t kept = n;
   u64 first_rank = 0;
+  u32 scan_lo = 0, scan_hi = dig1;
   if (shard && shard->parts > 1) {
     // This GPU keeps a stretch of the first digit's values: the `part`-th of `parts` stretches that hold about the
     // same number of suffixes each.  Every GPU counts the whole text and cuts the same way; nothing is exchanged.
@@ -1330,10 +1333,12 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
     kept = (size_t)(cum[hi] - cum[lo]);
     shard->first_rank = first_rank;
     shard->count = kept;
-    first.keep_lo = lo;
-    first.keep_hi = hi > lo ? hi : lo + 1;  // (an empty share keeps one digit that holds nothing)
-    if (lo > 0) HIP_CHECK(hipMemsetAsync(counts.get(), 0, (size_t)lo * nblk * sizeof(u32), c.stream));
-    if (hi < dig1) HIP_CHECK(hipMemsetAsync(counts.get() + (size_t)hi * nblk, 0, (size_t)(dig1 - hi) * nblk * sizeof(u32), c.stream));
+    // (an empty share -- both of its cuts fall inside one heavy digit, which the next share takes -- keeps a digit
+    // value that no element has)
+    first.keep_lo = hi > lo ? lo : dig1;
+    first.keep_hi = hi > lo ? hi : dig1 + 1;
+    scan_lo = first.keep_lo;  // only the rows of the digits kept are scanned, and read
+    scan_hi = hi > lo ? hi : dig1;
   } else if (shard) {
     shard->first_rank = 0;
     shard->count = n;
@@ -1355,7 +1360,8 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
       shard->bounds[1] = kept;
     }
   } else {
-    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, nullptr);
+    u32 *rows = counts.get() + (size_t)scan_lo * nblk;
+    scan_exclusive_u32(c, rows, rows, (size_t)(scan_hi - scan_lo) * nblk, nullptr);
   }
   if (kept_out) *kept_out = kept;
   const size_t room = kept > 0 ? kept : 1;
@@ -1373,7 +1379,7 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   const u32 nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
   DBuf<uint2> tmap(c, nblk2);
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
-                     tmap.get(), nblk2, rstart.get());
+                     tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi);
   HIP_CHECK(hipGetLastError());
   DBuf<u32> counts2(c, (size_t)(text.b2 > 9 ? 1024 : (text.b2 > 8 ? 512 : 256)) * nblk2);
   if (text.b2 > 9) lean_second_pass<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
