@@ -224,6 +224,12 @@ class Slice:
         _chk(lib().bwt_hip_slice_get_samples(self.ctx._h, self._h, _p(r, _i64p), _p(p, _i64p), self.n_samples))
         return r, p
 
+    def read_into(self, L_out, rank_out, pos_out):
+        """The slice's symbols and samples into the caller's arrays (for example page-locked memory)."""
+        assert L_out.dtype == np.uint8 and len(L_out) >= self.size and len(rank_out) >= self.n_samples and len(pos_out) >= self.n_samples
+        _chk(lib().bwt_hip_slice_get_L(self.ctx._h, self._h, _p(L_out, _u8p)))
+        _chk(lib().bwt_hip_slice_get_samples(self.ctx._h, self._h, _p(rank_out, _i64p), _p(pos_out, _i64p), self.n_samples))
+
     def free(self):
         if self._h:
             lib().bwt_hip_slice_free(self._h)

@@ -188,6 +188,53 @@ def verify_against_one_gpu(ctx, held, algo, rank, world, th, ns, seg, dist, dev,
     return out
 
 
+def host_to_host_native(ctx, transport, n, th, ns, seg, steps, dist, dev):
+    """The N > 1 build from host memory to host memory: on every rank the text goes up from page-locked host memory
+    (every GPU holds the whole text: n bytes over each GPU's own link, side by side), the ranks build, and every rank's
+    slice of L and its samples come down into page-locked host memory of that rank's process.  Seconds per build of
+    the slowest rank, between barriers."""
+    import numpy as np
+    import torch
+    import bwt_amd
+    Th = bwt_amd.HostBuffer(n)
+    ctx.read_text(Th.a)
+    s = ctx.dist_pmbwt(transport, th, ns, seg)
+    size, nsamp = s.size, s.n_samples
+    s.free()
+    Lh, Sr, Sp = bwt_amd.HostBuffer(max(1, size)), bwt_amd.HostBuffer(8 * max(1, nsamp)), bwt_amd.HostBuffer(8 * max(1, nsamp))
+    sr, sp = Sr.a.view(np.int64), Sp.a.view(np.int64)
+    ok = True
+
+    def once():
+        ctx.set_text(Th.a)
+        s = ctx.dist_pmbwt(transport, th, ns, seg)
+        good = s.size == size and s.n_samples == nsamp  # (the same tree every time)
+        if good:
+            s.read_into(Lh.a, sr, sp)
+        s.free()
+        return good
+
+    ok = once() and ok
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok = once() and ok
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    for b in (Th, Lh, Sr, Sp):
+        b.close()
+    per = float(dt.item()) / steps
+    return {"value": round((n - 1) / per / 1e6, 2), "unit": "Mbase/s", "ms_per_step": round(per * 1e3, 3), "steps": steps,
+            "what": "on every rank: T in page-locked host memory -> the GPU (n bytes over each GPU's own link, side by side) -> "
+                    "the build over all GPUs -> this rank's slice of L and its samples in page-locked host memory; slowest rank, between barriers",
+            "sanity": bool(int(flag.item()))}
+
+
 def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     """bench.py's N > 1 leg: strong scaling of one text over `world` GPUs.  --leaves is the leaf count of the
     whole tree (the same tree as on one GPU), so every rank builds leaves / world of them."""
@@ -324,6 +371,9 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
     if algo in ("native", "dist") and not os.environ.get("BWT_MGPU_NO_VERIFY"):
         verified = verify_against_one_gpu(ctx, last.d if algo == "dist" else last, algo, rank, world,
                                           leaf_threshold(n, total_leaves), ns, args.seg, dist, dev)
+    h2h = None
+    if algo == "native" and not getattr(args, "no_extras", False):
+        h2h = host_to_host_native(ctx, transport, n, leaf_threshold(n, total_leaves), ns, args.seg, args.steps, dist, dev)
     if rank == 0:
         from bwt_amd.benchutil import phase_table, roofline
         th = leaf_threshold(n, total_leaves)
@@ -352,6 +402,7 @@ def bench_main(args, rank, local_rank, world, metric, cpu_baseline):
             # outside the timed region: every rank's slice against the same tree built on that rank's GPU alone
             "verified_against_one_gpu": verified,
             "phases_rank0": phase_table(timers, args.steps),
+            "host_to_host": h2h,
         }
     if last is not None:
         last.free()
