@@ -30,6 +30,8 @@ def make(rng):
     world = int(rng.choice([2, 4, 8]))
     leaves = world * int(rng.choice([1, 1, 2, 4]))
     th = -(-n // leaves)
+    if rng.random() < 0.2:
+        th = n  # one leaf: the ranks share it by key range (with BWT_HIP_BUCKET_MIN_N=1 also at these sizes), or one rank builds it
     ns = int(rng.choice([2, 17, max(2, n // 100), max(2, n // 7), n]))
     seg = int(rng.choice([0, 7, 64, 1000, 4096]))
     return T, world, th, ns, seg
