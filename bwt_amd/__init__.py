@@ -69,6 +69,7 @@ def lib():
         "bwt_hip_gap": [vp, vp, vp, i64, _i64p, _i64p],
         "bwt_hip_dc_sample": [vp, i64, _i64p, _i64p, _i64p, C.POINTER(i32)],
         "bwt_hip_leaf_capacity": [vp, i64, _i64p],
+        "bwt_hip_symbol_codes": [vp, C.POINTER(i32), _u8p, _u8p],
         "bwt_hip_dist_leaf": [vp, i64, i64, i64, i32, i32, vp, i64, vp, _i64p, _i64p, _i64p, _i64p, _i64p, C.POINTER(i32)],
         "bwt_hip_block_ibwt": [vp, vp, _u8p, _i64p],
         "bwt_hip_block_sa": [vp, vp, i64, _i64p, _i64p],
@@ -348,6 +349,14 @@ class Context:
         SA = np.empty(b - a, dtype=np.int64)
         _chk(lib().bwt_hip_leaf_sa(self._h, a, b, _p(SA, _i64p)))
         return SA
+
+    def symbol_codes(self):
+        """(compact, code_of, symbol_of): whether the text is held with its symbols renumbered 1 .. sigma (scattered
+        alphabets), and the two tables (uint8[256]) between the text's symbols and the codes device buffers hold."""
+        compact = C.c_int32(0)
+        code_of, symbol_of = np.zeros(256, dtype=np.uint8), np.zeros(256, dtype=np.uint8)
+        _chk(lib().bwt_hip_symbol_codes(self._h, C.byref(compact), _p(code_of, _u8p), _p(symbol_of, _u8p)))
+        return bool(compact.value), code_of, symbol_of
 
     def dc_sample(self):
         """(period, positions, ranks) of the text's difference-cover sample: ranks[k] = rank of T[positions[k]:] among

@@ -95,6 +95,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_DEFER_CHAINS")) c.defer_chains = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_FILTER")) c.run_filter = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_COMPACT")) c.compact_allowed = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_DC")) c.dc_mode = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_BASE")) c.lean_base = atoi(v) != 0;
@@ -140,6 +141,7 @@ void bwt_hip_destroy(bwt_hip_ctx *ctx) {
   for (auto &kv : c.live_blocks) (void)hipFree(kv.first);
   if (c.h_scalars) (void)hipHostFree(c.h_scalars);
   if (c.d_scalars) (void)hipFree(c.d_scalars);
+  if (c.d_sym_tab) (void)hipFree(c.d_sym_tab);
   (void)hipStreamDestroy(c.stream);
   delete ctx;
 }
@@ -166,6 +168,7 @@ static void drop_text(Ctx &c) {
   c.T_owned = nullptr;
   c.T = nullptr;
   c.n = 0;
+  c.compact = false;
 }
 
 static void adopt_text(Ctx &c, const u8 *dT, i64 n) {
@@ -174,6 +177,40 @@ static void adopt_text(Ctx &c, const u8 *dT, i64 n) {
   text_stats(c, dT, n, &max_sym, &min_sym, &n_zero, &last);
   if (last != 0) fail(BWT_HIP_ETEXT, "text must end with a 0 byte (T[n-1] = %d)", last);
   if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
+  c.compact = false;
+  // Symbols scattered over the byte range (Ctx::compact): renumbered 1 .. sigma in their order, on the device copy.
+  // (Not for alphabets of up to four values wide -- nothing to gain -- and not where every value of the range occurs.)
+  if (c.compact_allowed && max_sym - min_sym >= 4) {
+    u32 present[8];
+    symbol_presence(c, dT, n, present);
+    int sigma = 0;
+    memset(c.sym_fwd, 0, sizeof(c.sym_fwd));
+    memset(c.sym_back, 0, sizeof(c.sym_back));
+    for (int v = 1; v < 256; v++)
+      if ((present[v >> 5] >> (v & 31)) & 1u) {
+        sigma++;
+        c.sym_fwd[v] = (u8)sigma;
+        c.sym_back[sigma] = (u8)v;
+      }
+    if (sigma < max_sym - min_sym + 1) {
+      if (!c.d_sym_tab) HIP_CHECK(hipMalloc((void **)&c.d_sym_tab, 512));
+      u8 both[512];
+      memcpy(both, c.sym_fwd, 256);
+      memcpy(both + 256, c.sym_back, 256);
+      HIP_CHECK(hipMemcpyAsync(c.d_sym_tab, both, 512, hipMemcpyHostToDevice, c.stream));
+      c.sync();  // `both` is on the stack
+      if (dT != c.T_owned) {  // the caller's memory stays as it is: a copy of the text, in codes
+        if (c.T_owned) c.release(c.T_owned);
+        c.T_owned = (u8 *)c.alloc((size_t)n + 64);
+        HIP_CHECK(hipMemsetAsync(c.T_owned + n, 0, 64, c.stream));
+      }
+      map_symbols(c, dT, c.T_owned, (u64)n, c.d_sym_tab);
+      dT = c.T_owned;
+      c.compact = true;
+      min_sym = 1;
+      max_sym = sigma;
+    }
+  }
   c.T = dT;
   c.n = n;
   c.max_sym = max_sym;
@@ -247,8 +284,21 @@ int bwt_hip_get_text(bwt_hip_ctx *ctx, uint8_t *T_host) {
   need(ctx && T_host, "ctx, T_host");
   Ctx &c = ctx->c;
   need(c.T != nullptr, "no text set");
-  HIP_CHECK(hipMemcpyAsync(T_host, c.T, (size_t)c.n, hipMemcpyDeviceToHost, c.stream));
-  c.sync();
+  HIP_CHECK(hipSetDevice(c.device));
+  symbols_to_host(c, c.T, (u64)c.n, T_host);
+  API_END
+}
+
+int bwt_hip_symbol_codes(bwt_hip_ctx *ctx, int *compact, uint8_t code_of[256], uint8_t symbol_of[256]) {
+  API_BEGIN
+  need(ctx != nullptr, "ctx");
+  Ctx &c = ctx->c;
+  need(c.T != nullptr, "no text set");
+  if (compact) *compact = c.compact ? 1 : 0;
+  for (int v = 0; v < 256; v++) {
+    if (code_of) code_of[v] = c.compact ? c.sym_fwd[v] : (u8)((v >= c.min_sym && v <= c.max_sym && v > 0) ? v : 0);
+    if (symbol_of) symbol_of[v] = c.compact ? c.sym_back[v] : (u8)((v >= c.min_sym && v <= c.max_sym && v > 0) ? v : 0);
+  }
   API_END
 }
 
@@ -335,20 +385,24 @@ int bwt_hip_leaf_capacity(bwt_hip_ctx *ctx, int64_t n, int64_t *max_leaf) {
 }
 
 // max symbol, smallest non-zero symbol and number of zeros of a host text, on a few host threads
-static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int max_threads) {
+// (*distinct, if not null: how many different non-zero symbols)
+static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int max_threads, int *distinct = nullptr) {
   unsigned hw = std::thread::hardware_concurrency();
   const int nt = n < (1 << 22) ? 1 : (hw > (unsigned)max_threads ? max_threads : (hw < 1 ? 1 : (int)hw));
   std::vector<u32> mx((size_t)nt, 0), mn((size_t)nt, 255);
   std::vector<i64> nz((size_t)nt, 0);
+  std::vector<u8> seen((size_t)nt * 256, 0);
   auto body = [&](int t) {
     const i64 lo = n * t / nt, hi = n * (t + 1) / nt;
     u8 m1 = 0, m0 = 255;  // m0: the smallest symbol counting 0 as 255 (v - 1 wraps)
     i64 z = 0;
+    u8 *mine = seen.data() + (size_t)t * 256;
     for (i64 i = lo; i < hi; i++) {
       const u8 v = T[i], w = (u8)(v - 1);
       m1 = v > m1 ? v : m1;
       m0 = w < m0 ? w : m0;
       z += (v == 0);
+      mine[v] = 1;
     }
     mx[(size_t)t] = m1;
     mn[(size_t)t] = m0;  // smallest (v - 1) over v != 0, or 255 if a 0 ... see below
@@ -368,6 +422,14 @@ static void host_text_stats(const u8 *T, i64 n, int *max_sym, int *min_sym, i64 
   *max_sym = (int)M;
   *min_sym = M ? (int)W + 1 : 0;
   *n_zero = Z;
+  if (distinct) {
+    *distinct = 0;
+    for (int v = 1; v < 256; v++) {
+      bool any = false;
+      for (int t = 0; t < nt; t++) any = any || seen[(size_t)t * 256 + (size_t)v];
+      *distinct += any;
+    }
+  }
 }
 
 int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64_t th, int64_t ns, int64_t seg,
@@ -468,9 +530,22 @@ int bwt_hip_pmbwt_host(bwt_hip_ctx *ctx, const uint8_t *T_host, int64_t n, int64
         // the text's statistics (which symbols occur decides the layout of every sort key and rank block) come from
         // the host copy while the first chunk is on its way
         i64 n_zero = 0;
-        host_text_stats(T_host, n, &max_sym, &min_sym, &n_zero, 16);
+        int distinct = 0;
+        host_text_stats(T_host, n, &max_sym, &min_sym, &n_zero, 16, &distinct);
         mark("text statistics done");
         if (n_zero != 1) fail(BWT_HIP_ETEXT, "text must hold exactly one 0 byte, found %ld", (long)n_zero);
+        if (c.compact_allowed && max_sym - min_sym >= 4 && distinct < max_sym - min_sym + 1) {
+          // Symbols scattered over the byte range (Ctx::compact): the whole text first, renumbered on the device, then
+          // the build; nothing of it runs under the upload.
+          drain();
+          adopt_text(c, c.T_owned, n);
+          std::unique_ptr<Block> blk(do_rec(c, 0, n, th, ns, seg));
+          if (L_host) symbols_to_host(c, blk->L.get(), (u64)n, L_host);
+          c.sync();
+          mark("L in host memory (renumbered alphabet)");
+          *out = publish(c, blk.release());
+          break;
+        }
       }
       c.T = c.T_owned;
       c.n = n;
@@ -546,6 +621,7 @@ int bwt_hip_block_upload(bwt_hip_ctx *ctx, int64_t a, int64_t b, const uint8_t *
     hp[(size_t)k] = (u32)samp_pos[k];
   }
   HIP_CHECK(hipMemcpyAsync(blk->L.get(), L_host, (size_t)(b - a), hipMemcpyHostToDevice, c.stream));
+  if (c.compact) map_symbols(c, blk->L.get(), blk->L.get(), (u64)(b - a), c.d_sym_tab);  // the text's symbols -> codes
   HIP_CHECK(hipMemcpyAsync(blk->samp_rank.get(), hr.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c.stream));
   HIP_CHECK(hipMemcpyAsync(blk->samp_pos.get(), hp.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c.stream));
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, c.T + (b - 1), 1, hipMemcpyDeviceToHost, c.stream));
@@ -645,7 +721,12 @@ int bwt_hip_block_info(const bwt_hip_block *blk_, int64_t *a, int64_t *b, int64_
   if (b) *b = blk->b;
   if (s_rank) *s_rank = blk->a + blk->s_rank;
   if (e_rank) *e_rank = blk->a + blk->e_rank;
-  if (e_char) *e_char = blk->e_char;
+  if (e_char) {
+    *e_char = blk->e_char;
+    std::lock_guard<std::mutex> lock(g_blocks_mu);
+    auto it = g_blocks.find(const_cast<Block *>(blk));
+    if (it != g_blocks.end() && it->second->compact) *e_char = it->second->sym_back[blk->e_char];  // the text's own symbol
+  }
   if (n_samples) *n_samples = blk->n_samp;
   API_END
 }
@@ -654,8 +735,8 @@ int bwt_hip_block_get_L(bwt_hip_ctx *ctx, const bwt_hip_block *blk_, uint8_t *L_
   API_BEGIN
   need(ctx && blk_ && L_host, "ctx, blk, L_host");
   const Block *blk = as_block(blk_);
-  HIP_CHECK(hipMemcpyAsync(L_host, blk->L.get(), (size_t)blk->len(), hipMemcpyDeviceToHost, ctx->c.stream));
-  ctx->c.sync();
+  HIP_CHECK(hipSetDevice(ctx->c.device));
+  symbols_to_host(ctx->c, blk->L.get(), (u64)blk->len(), L_host);
   API_END
 }
 
@@ -721,9 +802,19 @@ int bwt_hip_block_get_C(bwt_hip_ctx *ctx, bwt_hip_block *blk_, int alpha_max, in
   Block *blk = as_block(blk_);
   HIP_CHECK(hipSetDevice(ctx->c.device));
   count_alphabets(ctx->c, *blk);
-  if (ctx->c.max_sym > alpha_max)
-    fail(BWT_HIP_ETEXT, "text holds symbol %d above alpha_max %d", ctx->c.max_sym, alpha_max);
-  for (int k = 0; k <= alpha_max; k++) C_out[k] = blk->C[k];
+  const int top = ctx->c.compact ? (int)ctx->c.sym_back[ctx->c.max_sym] : ctx->c.max_sym;
+  if (top > alpha_max) fail(BWT_HIP_ETEXT, "text holds symbol %d above alpha_max %d", top, alpha_max);
+  if (ctx->c.compact) {
+    // C[k] = symbols below k: that of the smallest symbol of the text that is not below k
+    int code = ctx->c.max_sym + 1;  // (none: all of them are below)
+    for (int k = 255; k >= 0; k--) {
+      if (ctx->c.sym_fwd[k]) code = ctx->c.sym_fwd[k];
+      if (k == 0) code = 0;
+      if (k <= alpha_max) C_out[k] = blk->C[code];
+    }
+  } else {
+    for (int k = 0; k <= alpha_max; k++) C_out[k] = blk->C[k];
+  }
   API_END
 }
 
@@ -734,11 +825,20 @@ static void run_rank(Ctx &c, Block &blk, i64 nq, const uint8_t *sym, const int64
   for (i64 k = 0; k < nq; k++) {
     i64 p = lf ? pos[k] - blk.a : pos[k];
     if (p < 0 || p > m) fail(BWT_HIP_EINVAL, "query %ld: position %ld outside the block", (long)k, (long)pos[k]);
-    if ((int)sym[k] >> c.sym_bits) fail(BWT_HIP_EINVAL, "query %ld: symbol %d not in the text's alphabet", (long)k, (int)sym[k]);
+    if (!c.compact && ((int)sym[k] >> c.sym_bits)) fail(BWT_HIP_EINVAL, "query %ld: symbol %d not in the text's alphabet", (long)k, (int)sym[k]);
     hp[(size_t)k] = (u32)p;
   }
   DBuf<u8> ds(c, (size_t)nq);
   DBuf<u32> dp(c, (size_t)nq), dout(c, (size_t)nq);
+  std::vector<u8> codes;
+  if (c.compact) {  // the text's symbols -> codes
+    codes.resize((size_t)nq);
+    for (i64 k = 0; k < nq; k++) {
+      if (sym[k] && !c.sym_fwd[sym[k]]) fail(BWT_HIP_EINVAL, "query %ld: symbol %d not in the text's alphabet", (long)k, (int)sym[k]);
+      codes[(size_t)k] = c.sym_fwd[sym[k]];
+    }
+    sym = codes.data();
+  }
   HIP_CHECK(hipMemcpyAsync(ds.get(), sym, (size_t)nq, hipMemcpyHostToDevice, c.stream));
   HIP_CHECK(hipMemcpyAsync(dp.get(), hp.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c.stream));
   rank_batch(c, blk, ds.get(), dp.get(), dout.get(), (size_t)nq, lf);
@@ -777,10 +877,7 @@ int bwt_hip_block_ibwt(bwt_hip_ctx *ctx, bwt_hip_block *blk_, uint8_t *I_host, i
   i64 bad = 0;
   inverse_block(c, blk, out.get(), mismatches ? &bad : nullptr);
   if (mismatches) *mismatches = bad;
-  if (I_host) {
-    HIP_CHECK(hipMemcpyAsync(I_host, out.get(), (size_t)blk.len(), hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-  }
+  if (I_host) symbols_to_host(c, out.get(), (u64)blk.len(), I_host);
   API_END
 }
 

@@ -255,4 +255,97 @@ void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_
   *last = lastc;
 }
 
+__global__ void __launch_bounds__(256) k_symbol_presence(const u8 *__restrict__ T, u64 n, u32 *__restrict__ present) {
+  u64 seen[4] = {0, 0, 0, 0};
+  const u64 words = n / 16;
+  for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q <= words; q += (u64)gridDim.x * 256) {
+    u32 w[4] = {0, 0, 0, 0};
+    u32 count = 16;
+    if (q < words) {
+      const uint4 v = reinterpret_cast<const uint4 *>(T)[q];  // (the text is 16-byte aligned)
+      w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+      count = (u32)(n - words * 16);
+      for (u32 k = 0; k < count; k++) w[k >> 2] |= (u32)T[words * 16 + k] << (8 * (k & 3));
+    }
+    for (u32 k = 0; k < count; k++) {
+      const u32 v = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+      const u64 bit = 1ull << (v & 63u);
+      seen[0] |= (v >> 6) == 0 ? bit : 0ull;
+      seen[1] |= (v >> 6) == 1 ? bit : 0ull;
+      seen[2] |= (v >> 6) == 2 ? bit : 0ull;
+      seen[3] |= (v >> 6) == 3 ? bit : 0ull;
+    }
+  }
+  for (int k = 0; k < 4; k++) {
+    u32 lo = (u32)seen[k], hi = (u32)(seen[k] >> 32);
+    for (int o = 32; o > 0; o >>= 1) {
+      lo |= (u32)__shfl_xor(lo, o, 64);
+      hi |= (u32)__shfl_xor(hi, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (lo) atomicOr(&present[2 * k], lo);
+      if (hi) atomicOr(&present[2 * k + 1], hi);
+    }
+  }
+}
+
+void symbol_presence(Ctx &c, const u8 *dT, i64 n, u32 present[8]) {
+  u32 *d = c.d_scalars + 40;
+  HIP_CHECK(hipMemsetAsync(d, 0, 32, c.stream));
+  const u32 blocks = (u32)std::min<u64>(ceil_div((u64)n / 16 + 1, 256 * 8), (u64)c.n_cu * 16);
+  hipLaunchKernelGGL(k_symbol_presence, dim3(blocks ? blocks : 1), dim3(256), 0, c.stream, dT, (u64)n, d);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars + 40, d, 32, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  for (int k = 0; k < 8; k++) present[k] = c.h_scalars[40 + k];
+}
+
+// (src and dst 16-byte aligned)
+__global__ void __launch_bounds__(256) k_map_symbols(const u8 *__restrict__ src, u8 *__restrict__ dst, u64 n, const u8 *__restrict__ table) {
+  __shared__ u8 tab[256];
+  tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const u64 words = n / 16;
+  for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q <= words; q += (u64)gridDim.x * 256) {
+    if (q < words) {
+      const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
+      u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        w[k] = (u32)tab[w[k] & 255u] | ((u32)tab[(w[k] >> 8) & 255u] << 8) | ((u32)tab[(w[k] >> 16) & 255u] << 16) | ((u32)tab[w[k] >> 24] << 24);
+      reinterpret_cast<uint4 *>(dst)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (u64 i = words * 16; i < n; i++) dst[i] = tab[src[i]];
+    }
+  }
+}
+
+void map_symbols(Ctx &c, const u8 *src, u8 *dst, u64 n, const u8 *d_table) {
+  if (n == 0) return;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) fail(BWT_HIP_EINTERNAL, "map_symbols: unaligned buffers");
+  const u32 blocks = (u32)std::min<u64>(ceil_div(n / 16 + 1, 256 * 4), (u64)c.n_cu * 32);
+  hipLaunchKernelGGL(k_map_symbols, dim3(blocks ? blocks : 1), dim3(256), 0, c.stream, src, dst, n, d_table);
+  HIP_CHECK(hipGetLastError());
+}
+
+void symbols_to_host(Ctx &c, const u8 *src_dev, u64 count, u8 *dst_host) {
+  if (count == 0) return;
+  if (!c.compact) {
+    HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, (size_t)count, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return;
+  }
+  // through a buffer of at most 256 MB, piece by piece (the source may begin at any address: a slice of L)
+  const u64 piece = std::min<u64>(count, 256ull << 20);
+  DBuf<u8> tmp(c, (size_t)piece + 32);
+  for (u64 at = 0; at < count; at += piece) {
+    const u64 len = std::min<u64>(piece, count - at);
+    const u32 off = (u32)((uintptr_t)(src_dev + at) & 15);  // the aligned block in front of the piece is the source's own memory or the pool's
+    map_symbols(c, src_dev + at - off, tmp.get(), len + off, c.d_sym_tab + 256);
+    HIP_CHECK(hipMemcpyAsync(dst_host + at, tmp.get() + off, (size_t)len, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+  }
+}
+
 }  // namespace bwtamd

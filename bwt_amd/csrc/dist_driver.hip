@@ -820,8 +820,7 @@ int bwt_hip_slice_get_L(bwt_hip_ctx *ctx, const bwt_hip_slice *s_, uint8_t *L_ho
   const Slice *s = reinterpret_cast<const Slice *>(s_);
   const i64 size = s->d->sizes[(size_t)s->rank];
   HIP_CHECK(hipSetDevice(ctx->c.device));
-  if (size > 0) HIP_CHECK(hipMemcpyAsync(L_host, s->d->L.get(), (size_t)size, hipMemcpyDeviceToHost, ctx->c.stream));
-  ctx->c.sync();
+  if (size > 0) symbols_to_host(ctx->c, s->d->L.get(), (u64)size, L_host);
   DIST_END
 }
 

@@ -75,6 +75,15 @@ struct Ctx {
   int max_sym = 0;  // largest symbol in T
   int min_sym = 0;  // smallest symbol in T besides the terminator (0 if there is none)
   int sym_bits = 0; // bits per symbol = floor(log2(max_sym)) + 1
+  // A text whose symbols are scattered over the byte range (letters: A, C, G, T are 65, 67, 71, 84) is held on the
+  // device with its symbols renumbered 1 .. sigma in their order (compact): keys, rank structures and wire formats then
+  // see a dense alphabet -- as ASCII, DNA would spend five bits a symbol where two do.  Everything inside the library,
+  // the blocks' L included, is in those codes; symbols are translated where they enter or leave through host memory
+  // (sym_fwd: symbol -> code, 0 for symbols the text does not hold; sym_back: code -> symbol; d_sym_tab: both on the
+  // device, 256 bytes each).
+  bool compact_allowed = true, compact = false;
+  u8 sym_fwd[256] = {}, sym_back[256] = {};
+  u8 *d_sym_tab = nullptr;
 
   // A text that is still arriving (bwt_hip_pmbwt_host): its upload runs on `copy_stream` in chunks, each with
   // an event; wait_text(upto) makes `stream` wait for the chunks that cover T[0:upto) before work that reads
@@ -532,6 +541,12 @@ void download_samples32(Ctx &c, const u32 *rank, const u32 *pos, i64 k, i64 a, i
 
 void device_gen_text(Ctx &c, u8 *dT, i64 n, u64 seed, int sigma);
 void text_stats(Ctx &c, const u8 *dT, i64 n, int *max_sym, int *min_sym, i64 *n_zero, int *last);
+// present[v >> 5] bit v & 31: the text holds symbol v
+void symbol_presence(Ctx &c, const u8 *dT, i64 n, u32 present[8]);
+// dst[i] = table[src[i]] (table: 256 bytes on the device; dst may be src)
+void map_symbols(Ctx &c, const u8 *src, u8 *dst, u64 n, const u8 *d_table);
+// count symbols from device memory to host memory, codes turned back into the text's own symbols where it is compact
+void symbols_to_host(Ctx &c, const u8 *src_dev, u64 count, u8 *dst_host);
 struct WmView;
 WmView make_view(const Block &blk);
 

@@ -1760,6 +1760,7 @@ void ensure_dc_sample(Ctx &c) {
                        (const u32 *)vals[cur], 0u, (u32)N, isa.get());
     if (R.M > 0) hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(R.M, 256)), dim3(256), 0, c.stream, R.wl_pos, R.wl_grp, R.M, 0u, isa.get());
     HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(c.d_scalars + 9, 0, sizeof(u32), c.stream));  // the rounds' overflow flag (an earlier sort may have left it raised)
     if (!doubling_rounds(c, R, "dc_doubling_round")) fail(BWT_HIP_EINTERNAL, "difference-cover sample: a look-up beyond the text");
     c.sync();  // the sort's buffers die here
   }

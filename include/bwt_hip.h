@@ -73,6 +73,17 @@ int bwt_hip_gen_text(bwt_hip_ctx *ctx, int64_t n, uint64_t seed, int sigma);
 /* Copies the context's text back to the host (n bytes). */
 int bwt_hip_get_text(bwt_hip_ctx *ctx, uint8_t *T_host);
 
+/* A text whose symbols are scattered over the byte range (letters: A, C, G, T are 65, 67, 71, 84) is held on the
+   device with its symbols renumbered 1 .. sigma in their order, so that sort keys, rank structures and the transfers
+   between GPUs see a dense alphabet; the reference instead sizes everything by alpha_max (include/bwt.h:200-226,
+   wavelet_matrix.h:95-110).  Every entry point that takes or returns symbols in HOST memory (the text, L, e_char,
+   C[], the symbols of rank and LF queries, decoded blocks) uses the text's own symbols.  DEVICE memory that the
+   library hands out or takes (bwt_hip_block_L_device, _export_device, _import_device, the bwt_hip_dist_* steps,
+   bwt_hip_slice_L_device) holds the codes.  *compact = 1 if the current text is renumbered; code_of[v] = code of
+   symbol v (0: not in the text), symbol_of[k] = symbol of code k; either table may be null.  No counterpart in the
+   reference.  BWT_HIP_COMPACT=0 in the environment switches the renumbering off. */
+int bwt_hip_symbol_codes(bwt_hip_ctx *ctx, int *compact, uint8_t code_of[256], uint8_t symbol_of[256]);
+
 /* ---- the pipeline ------------------------------------------------------ */
 
 /* bwt::bwt_leaf (include/bwt.h:615-635): BWT of T[a:b) from its suffix array
