@@ -61,6 +61,38 @@ int main() {
     printf("OK pmbwt default budget\n");
     delete[] T; delete[] L; delete[] I;
   }
+  {  // DNA as letters (65, 67, 71, 84: the device holds such a text renumbered, the host never sees the codes):
+     // the pipeline's round trip, and a merge of blocks that only exist on the host
+    bwt::idx_t n = 120000;
+    bwt::alpha_t * T = gen(n, 11, 4), * L = new bwt::alpha_t[n], * I = new bwt::alpha_t[n];
+    const bwt::alpha_t letters[5] = {0, 'A', 'C', 'G', 'T'};
+    for (bwt::idx_t i = 0; i < n; i++) T[i] = letters[T[i]];
+    bwt::bwt_opt opt;
+    opt.set_defaults(T, n);
+    bwt::mallocator mem(n, opt);
+    bwt::bwt t = bwt::pmbwt(T, n, L, 0, mem, opt);
+    for (bwt::idx_t r = 0; r < n; r++)
+      if (L[r] != 0 && L[r] != 'A' && L[r] != 'C' && L[r] != 'G' && L[r] != 'T') return fail("L holds the text's own symbols");
+    t.init_extra(0, mem, opt);
+    t.ibwt(I);
+    if (!bwt::check_equal(T, I, 0, n)) return fail("letters round trip");
+    for (bwt::idx_t r = 0; r < n; r += 4999)
+      if (L[r] != (t.sa(r) ? T[t.sa(r) - 1] : 0)) return fail("letters: L[r] = T[sa(r)-1]");
+    t.fini(mem, opt);
+    bwt::idx_t a = 0, c = 50000;
+    bwt::bwt l = bwt::bwt_leaf(T, n, a, c, L, mem, opt);
+    bwt::bwt r = bwt::bwt_leaf(T, n, c, n, L, mem, opt);
+    bwt_hip_block_free(bwt::device_session::get().ctx, l.dev); l.dev = 0;
+    bwt_hip_block_free(bwt::device_session::get().ctx, r.dev); r.dev = 0;
+    bwt::bwt m = bwt::bwt_merge(l, r, 0, mem, opt);
+    memset(I, 0, n);
+    m.init_extra(0, mem, opt);
+    m.ibwt(I);
+    if (!bwt::check_equal(T, I, 0, n)) return fail("letters: merge of host blocks");
+    m.fini(mem, opt);
+    printf("OK letters\n");
+    delete[] T; delete[] L; delete[] I;
+  }
   {  // two leaves of a sub-range and their merge (src/test/test_merge.cc), blocks kept in HBM
     bwt::idx_t n = 50000, a = 1234, b = 43210, c = (a + b) / 2;
     bwt::alpha_t * T = gen(n, 7, 26), * M = new bwt::alpha_t[n], * I = new bwt::alpha_t[n];
