@@ -96,6 +96,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_REPEAT_PROBE")) c.repeat_probe = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_FILTER")) c.run_filter = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_COMPACT")) c.compact_allowed = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_DEFER_BUCKETS")) c.defer_buckets = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_DC")) c.dc_mode = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_BASE")) c.lean_base = atoi(v) != 0;

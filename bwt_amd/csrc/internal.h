@@ -141,6 +141,7 @@ struct Ctx {
   bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
   bool repeat_probe = true;
+  bool defer_buckets = true;  // the lean route's buckets with too many equal keys go to a general kernel instead of failing the route (off: tests)
   bool run_filter = true;  // long runs of one symbol leave the lean route's sort and are ranked in closed form (off: tests)
   // Ranks of a difference-cover sample of the whole text (DcSample below), built on first use by a leaf whose ties are
   // dense: 0 never, 1 when a leaf asks for them, 2 for every leaf that has ties at all (tests)
@@ -327,11 +328,11 @@ struct TextKeys {
   // order is known in closed form, suffix_sort.hip); low byte of run_lo zero
   u64 run_lo, run_span;
   // ... and whose first run_k symbols really are run_sym (a key alone cannot always tell: the terminator, or
-  // code_max).  code_max != 0 (bit-field codes only): the run symbol, the alphabet's largest and rare outside its
-  // runs, has no code of its own, so that the keys use the key space of the alphabet without it: where it stands a
-  // key shows code_max, the code of the symbol below it, and the same for every symbol behind it -- "that symbol,
-  // then nothing larger" -- which keeps the keys in the order of the suffixes; equal keys then need not be equal
-  // symbols.
+  // code_max).  code_max != 0 (bit-field codes only): run_sym, rare outside its runs or altogether, has no code of its
+  // own, so that the keys use the key space of the alphabet without it: the symbols above it are coded one lower, and
+  // where it stands itself a key shows the code of the symbol below it and, for every symbol behind it, the largest
+  // code -- "that symbol, then nothing larger" -- which keeps the keys in the order of the suffixes; equal keys then
+  // need not be equal symbols.
   u32 run_sym, run_k, code_max;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);

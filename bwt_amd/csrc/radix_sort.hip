@@ -83,7 +83,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   const int lsh = 64 - used;
   const u32 ms = tk.min_sym - (u32)tk.one_based;  // code(c) = c - ms for a symbol, 0 for the terminator
   const u32 code_max = RUNF ? tk.code_max : 0u;
-  const u32 cm = code_max ? code_max : 0xFFu;  // (TextKeys::code_max)
+  const u32 skip = code_max ? tk.run_sym : 0x100u;  // (TextKeys::code_max: symbols from here on are coded one lower)
   const u32 *src = S32 + (TK_LEAD + k0) / 4;
   const u8 *raw = reinterpret_cast<const u8 *>(S32) + TK_LEAD + k0;
   if (w == 2 && !tk.one_based && !tk.base && K0 + ITEMS <= 32) {
@@ -102,11 +102,12 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
         const u32 x = src[q];
         if (q < WORDS / 2 + 1) wds[q] = x;
         plain = plain && !((x - 0x01010101u) & ~x & 0x80808080u);
-        if (code_max) {  // a symbol whose code is not c - min_sym: the byte loop
+        u32 y = x - tk.min_sym * 0x01010101u;
+        if (code_max) {  // a word that holds the symbol without a code takes the byte loop; larger symbols are coded one lower
           const u32 z = x ^ (tk.run_sym * 0x01010101u);
           plain = plain && !((z - 0x01010101u) & ~z & 0x80808080u);
+          y -= (((x | 0x80808080u) - tk.run_sym * 0x01010101u) & 0x80808080u) >> 7;  // (symbols below 128: codes that fit two bits)
         }
-        const u32 y = x - tk.min_sym * 0x01010101u;
         codes = (codes << 8) | (((y & 0x03030303u) * 0x40100401u) >> 24);
       }
     }
@@ -130,14 +131,14 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
     for (int k = 0; k < K0; k++) {
       if ((k & 3) == 0) wd = src[k >> 2];
       const u32 ch = wd & 255u;
-      sf = sf * B + (ch ? min(ch - ms, cm) : 0u);
+      sf = sf * B + (ch ? ch - ms - (u32)(ch >= skip) : 0u);
       wd >>= 8;
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
       key_out[j] = ((sf * tk.scale) << 8) | raw[j - 1];
       const u32 out = raw[j], in = raw[K0 + j];
-      sf = (sf - (u64)(out ? min(out - ms, cm) : 0u) * tk.lead) * B + (in ? min(in - ms, cm) : 0u);
+      sf = (sf - (u64)(out ? out - ms - (u32)(out >= skip) : 0u) * tk.lead) * B + (in ? in - ms - (u32)(in >= skip) : 0u);
     }
     return;
   }
@@ -147,7 +148,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
   for (int k = 0; k < K0; k++) {
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
-    sf = (sf << w) | (ch ? min(ch - ms, cm) : 0u);
+    sf = (sf << w) | (ch ? ch - ms - (u32)(ch >= skip) : 0u);
     if (code_max) shared |= (u64)(ch == tk.run_sym) << k;
     wd >>= 8;
   }
@@ -159,7 +160,7 @@ __device__ __forceinline__ void tk_roll(const u32 *S32, u32 k0, const TextKeys &
     const int k = K0 + j;
     if ((k & 3) == 0) wd = src[k >> 2];
     u32 ch = wd & 255u;
-    sf = ((sf << w) | (ch ? min(ch - ms, cm) : 0u)) & maskall;
+    sf = ((sf << w) | (ch ? ch - ms - (u32)(ch >= skip) : 0u)) & maskall;
     if (code_max) shared = (shared >> 1) | ((u64)(ch == tk.run_sym) << (K0 - 1));
     wd >>= 8;
   }
@@ -825,12 +826,12 @@ __global__ void k_bucket_histogram(TextKeys tk, u64 first, u64 count, u64 stride
   const u64 p = first + (t >> 4) * stride + (t & 15);
   const u32 ms = tk.min_sym - (u32)tk.one_based;
   u64 sf = 0;
-  const u32 cm = tk.code_max ? tk.code_max : 0xFFu;
+  const u32 skip = tk.code_max ? tk.run_sym : 0x100u, top = (1u << tk.w) - 1u;
   u32 copies = 0;  // of the run symbol at the suffix's start
   bool seen = false;  // code_max: a symbol that shares its code has gone by; the largest code from there on
   for (int k = 0; k < tk.K0; k++) {
     const u32 ch = p + k < tk.n ? tk.T[p + k] : 0u;
-    const u32 code = seen ? cm : (ch ? min(ch - ms, cm) : 0u);
+    const u32 code = seen ? top : (ch ? ch - ms - (u32)(ch >= skip) : 0u);
     if (tk.base) sf = sf * tk.base + code;
     else sf = (sf << tk.w) | code;
     copies += (copies == (u32)k && ch == tk.run_sym);

@@ -153,6 +153,8 @@ struct LeanView {
   __device__ __forceinline__ u32 elem_pos(u64 x) const { return a + ((u32)x & posmask); }
   __device__ __forceinline__ u32 elem_prev(u64 x, u32) const { return (u32)(x >> pbits) & vmask; }
   __device__ __forceinline__ u32 extra(u64 x) const { return xbits ? (u32)((x << (b2 + 16)) >> (64 - xbits)) : 0u; }
+  // all key bits an element of a bucket shows below the bucket's own (what bucket_key and extra split)
+  __device__ __forceinline__ u64 sort_bits(u64 x) const { return (x << b2) >> (48 - xbits); }
 };
 
 __device__ __host__ inline void set_positions(PairsView &, const u32 *) {}
@@ -668,6 +670,9 @@ struct LeafEmit : EmitParams {
   u64 h;             // direct_tied(): depth of the round-0 keys
   u32 leaf_end;      // direct_tied(): positions at or beyond it are window slack, not part of the leaf
   u32 *fail;         // direct_tied(): raised when a group is too large or a comparison too long
+  // the bucket kernel's way out for a bucket with too many equal keys (null: it raises *fail): the bucket's number
+  // goes on this list, *defer_count counts them, and k_bucket_general takes those buckets afterwards
+  u32 *defer_list, *defer_count;
 
   double samp_ratio; // (ns-1)/(m-1), only used to skip positions that are certainly not sampled
 
@@ -751,8 +756,10 @@ struct LeafEmit : EmitParams {
   // the pass waits on the latency of these reads, not on their number.)
   // lds_L (with the leaf rank of its first byte): where L[r] goes instead of memory, for a caller that stores its
   // stretch of L itself afterwards
+  // soft (may be null): where a group that is too large is reported instead of *fail (the caller has another way)
   template <class Window>
-  __device__ __forceinline__ void direct_tied(const Window &w, u64 i, u32 slack_before, u8 *lds_L = nullptr, u64 lds_first = 0) const {
+  __device__ __forceinline__ void direct_tied(const Window &w, u64 i, u32 slack_before, u8 *lds_L = nullptr, u64 lds_first = 0,
+                                              u32 *soft = nullptr) const {
     if (*reinterpret_cast<volatile u32 *>(fail)) return;  // someone gave up already
     const u64 kfull = w.key(i);
     const u64 k = kfull & sym_mask;
@@ -761,7 +768,8 @@ struct LeafEmit : EmitParams {
     while (gs > 0 && i - gs < DF_GROUP && (w.key(gs - 1) & sym_mask) == k) gs--;
     while (ge + 1 < N && ge - i < DF_GROUP && (w.key(ge + 1) & sym_mask) == k) ge++;
     if (i - gs >= DF_GROUP || ge - i >= DF_GROUP) {
-      *fail = 1;
+      if (soft) *soft = 1;
+      else *fail = 1;
       return;
     }
     u32 smaller = 0, slack_smaller = 0, slack_ahead = 0;
@@ -1088,6 +1096,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   __shared__ u64 tied_mask[BK_MASKS], slack_mask[SLACK ? BK_MASKS : 1];
   __shared__ u32 tied_pre[BK_MASKS + 1], slack_pre[SLACK ? BK_MASKS : 1];
   __shared__ u32 scan_s[4];
+  __shared__ u32 soft_s;  // a tied group too large for the direct comparisons: the bucket goes on the list of deferred ones
   // The bucket's stretch of L is collected here and leaves as aligned 16-byte stores (one byte per lane, and none
   // for the tied suffixes in between, left memory with partly written sectors: twice the bytes on the way out).
   // Byte j of the stretch lies at lsym[lead + j], lead = its address modulo 16, so that aligned groups of the array
@@ -1125,7 +1134,10 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     }
     reinterpret_cast<uint4 *>(nib)[tid * 2] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4 *>(nib)[tid * 2 + 1] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) scan_s[3] = 0;
+    if (tid == 0) {
+      scan_s[3] = 0;
+      soft_s = 0;
+    }
     if (tid < BK_MASKS) {
       tied_mask[tid] = 0;
       if (SLACK) slack_mask[tid] = 0;
@@ -1145,7 +1157,10 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     if (full) scan_s[3] = 1;
     lds_barrier();
     if (scan_s[3]) {  // the same for every thread
-      if (tid == 0) *E.fail = 1;
+      if (tid == 0) {
+        if (!SLACK && E.defer_list) E.defer_list[atomicAdd(E.defer_count, 1u)] = blockIdx.x;
+        else *E.fail = 1;
+      }
       return;
     }
     {
@@ -1259,8 +1274,16 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     const u32 idx = lo * 64 + select_bit(tied_mask[lo], t - tied_pre[lo]);
     u32 sb = below;
     if (SLACK) sb += slack_pre[idx >> 6] + (u32)__popcll(slack_mask[idx >> 6] & ((1ull << (idx & 63)) - 1ull));
-    if constexpr (STAGE_L) E.direct_tied(win, (u64)s + idx, sb, lsym + lead, (u64)s);
-    else E.direct_tied(win, (u64)s + idx, sb);
+    u32 *soft = (!SLACK && E.defer_list) ? &soft_s : nullptr;
+    if constexpr (STAGE_L) E.direct_tied(win, (u64)s + idx, sb, lsym + lead, (u64)s, soft);
+    else E.direct_tied(win, (u64)s + idx, sb, nullptr, 0, soft);
+  }
+  if (!SLACK && E.defer_list) {
+    lds_barrier();
+    if (soft_s) {  // (what the bucket has written so far is written again, the same or right, by k_bucket_general)
+      if (tid == 0) E.defer_list[atomicAdd(E.defer_count, 1u)] = blockIdx.x;
+      return;
+    }
   }
   if constexpr (STAGE_L) {
     if (!E.L) return;
@@ -1276,6 +1299,53 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
         for (u32 j = lo; j < hi; j++) g0[j] = lsym[j];
       }
     }
+  }
+}
+
+// A bucket the kernel above has given up on (a key value more than 15 times, a tied group of more than DF_GROUP): all of
+// it in LDS, ordered by a bitonic network whose comparison is the elements' key bits first and the text behind them
+// second -- any number of equal keys, as long as the comparisons themselves stay short (*E.fail otherwise).  Slow per
+// element and meant for the few buckets that need it.
+constexpr int BG_THREADS = 1024;
+constexpr int BG_CAP = 16384;  // the largest bucket (BK_CAP) rounded up to a power of two
+
+__global__ void __launch_bounds__(BG_THREADS) k_bucket_general(LeafEmit<LeanView> E, const u32 *__restrict__ start, const u32 *__restrict__ list) {
+  __shared__ u64 buf[BG_CAP];
+  const u32 b = list[blockIdx.x];
+  const u32 s = start[b], cnt = start[b + 1] - s;
+  const u32 tid = threadIdx.x;
+  u32 n2 = 2;
+  while (n2 < cnt) n2 <<= 1;
+  for (u32 i = tid; i < n2; i += BG_THREADS) buf[i] = i < cnt ? E.v.e[s + i] : ~0ull;  // (all ones: no element; they end up last)
+  __syncthreads();
+  auto less = [&](u64 x, u64 y) -> bool {
+    if (x == ~0ull || y == ~0ull) return x != ~0ull && y == ~0ull;
+    const u64 kx = E.v.sort_bits(x), ky = E.v.sort_bits(y);
+    if (kx != ky) return kx < ky;
+    bool decided;
+    const bool lt = text_less(E.T, E.n, (u64)E.v.elem_pos(x) + E.h, (u64)E.v.elem_pos(y) + E.h, &decided, E.runs, E.n_runs);
+    if (!decided) *E.fail = 1;
+    return lt;
+  };
+  for (u32 k = 2; k <= n2; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      for (u32 i = tid; i < n2; i += BG_THREADS) {
+        const u32 p = i ^ j;
+        if (p > i) {
+          const u64 x = buf[i], y = buf[p];
+          const bool up = (i & k) == 0;
+          if (up ? less(y, x) : less(x, y)) {
+            buf[i] = y;
+            buf[p] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (u32 i = tid; i < cnt; i += BG_THREADS) {
+    const u64 x = buf[i];
+    E.place((u64)s + i, E.v.elem_pos(x), E.v.elem_prev(x, 0u));
   }
 }
 
@@ -2320,30 +2390,67 @@ static int try_wide_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
 struct RunPlan {
   bool on = false;
   u32 sym = 0;  // the symbol whose runs are taken out
-  // The symbol is the alphabet's largest and rare outside its runs (the N of an assembly, coded behind the bases): the
-  // keys then give it the code of the symbol below it (TextKeys::code_max) and use the key space of the alphabet
-  // without it -- with a code of its own that hardly ever occurs, a fifth symbol leaves four fifths of the key space
-  // empty at every digit, and the buckets that are used overflow.
+  // The symbol is rare outside its runs, or rare altogether (the N of an assembly): the keys then give it no code of
+  // its own (TextKeys::code_max) and use the key space of the alphabet without it -- with a code that hardly ever
+  // occurs, a fifth symbol leaves four fifths of the key space empty at every digit, and the buckets that are used
+  // overflow.  Every suffix that begins with it is then in the block.
   bool merge = false;
 };
 
-// *out += the positions of [a, b) that hold sym
+// out[0] += the positions of [a, b) that hold sym, out[1] += those that hold a smaller symbol (the terminator too)
 __global__ void __launch_bounds__(256) k_count_symbol(const u8 *__restrict__ T, u64 a, u64 b, u32 sym, u32 *__restrict__ out) {
-  u32 mine = 0;
+  u32 mine = 0, below = 0;
   for (u64 p = a + ((u64)blockIdx.x * 256 + threadIdx.x) * 8; p < b; p += (u64)gridDim.x * 256 * 8) {
+    u64 w = 0;
+    u32 count = 8;
     if (p + 8 <= b) {
-      u64 w;
       __builtin_memcpy(&w, T + p, 8);
-      const u64 x = w ^ (0x0101010101010101ull * sym);
-      u64 t = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
-      t = ~(t | x | 0x7F7F7F7F7F7F7F7Full);
-      mine += (u32)__popcll(t);
     } else {
-      for (u64 q = p; q < b; q++) mine += T[q] == sym;
+      count = (u32)(b - p);
+      for (u32 k = 0; k < count; k++) w |= (u64)T[p + k] << (8 * k);
+    }
+    for (u32 k = 0; k < count; k++) {
+      const u32 v = (u32)(w >> (8 * k)) & 255u;
+      mine += v == sym;
+      below += v < sym;
     }
   }
   mine = wave_reduce_sum(mine);
-  if (lane_id() == 0 && mine) atomicAdd(out, mine);
+  below = wave_reduce_sum(below);
+  if (lane_id() == 0) {
+    if (mine) atomicAdd(out, mine);
+    if (below) atomicAdd(out + 1, below);
+  }
+}
+
+// out[v] += the positions of [a, b) that hold symbol v, for v < 16 (alphabets of a few symbols)
+__global__ void __launch_bounds__(256) k_count_symbols16(const u8 *__restrict__ T, u64 a, u64 b, u32 *__restrict__ out) {
+  __shared__ u32 tot[16];
+  if (threadIdx.x < 16) tot[threadIdx.x] = 0;
+  __syncthreads();
+  u64 lo = 0, hi = 0;  // sixteen 8-bit counters, flushed before they can wrap
+  u32 since = 0;
+  auto flush = [&]() {
+    for (u32 v = 0; v < 8; v++) {
+      const u32 x = (u32)(lo >> (8 * v)) & 255u, y = (u32)(hi >> (8 * v)) & 255u;
+      if (x) atomicAdd(&tot[v], x);
+      if (y) atomicAdd(&tot[8 + v], y);
+    }
+    lo = hi = 0;
+    since = 0;
+  };
+  for (u64 p = a + ((u64)blockIdx.x * 256 + threadIdx.x) * 8; p < b; p += (u64)gridDim.x * 256 * 8) {
+    const u32 count = p + 8 <= b ? 8u : (u32)(b - p);
+    for (u32 k = 0; k < count; k++) {
+      const u32 v = T[p + k];
+      if (v < 8) lo += 1ull << (8 * v);
+      else if (v < 16) hi += 1ull << (8 * (v - 8));
+    }
+    if (++since == 31) flush();
+  }
+  flush();
+  __syncthreads();
+  if (threadIdx.x < 16 && tot[threadIdx.x]) atomicAdd(&out[threadIdx.x], tot[threadIdx.x]);
 }
 
 // the listed runs of one symbol that meet [a, b): worth it from 4096 positions on; the symbol of the longest
@@ -2363,7 +2470,12 @@ static RunPlan plan_run_filter(Ctx &c, i64 a, i64 b) {
     }
   }
   rp.on = best >= 4096 && rp.sym != 0;
-  if (rp.on && (int)rp.sym == c.max_sym && c.max_sym > c.min_sym + 1 && c.min_sym > 0) {
+  // No code of its own for a symbol that is rare (RunPlan::merge): only where the alphabet without it has 2^k symbols
+  // (bit-field codes), the symbol is not the smallest (its place in a key is taken by the symbol below it) and all
+  // symbols are below 128 (the key roll's byte arithmetic).
+  const int span = c.max_sym - c.min_sym;
+  const bool fits = c.min_sym > 0 && span >= 2 && (span & (span - 1)) == 0 && c.max_sym < 128;
+  if (rp.on && fits && (int)rp.sym > c.min_sym) {
     i64 covered = 0;  // by the listed runs of this symbol
     for (size_t i = 0; i < cnt; i++) {
       if (c.runs_host[2 * cnt + i] != 1 || c.runs_host[3 * cnt + i] != rp.sym) continue;
@@ -2371,12 +2483,28 @@ static RunPlan plan_run_filter(Ctx &c, i64 a, i64 b) {
       const i64 lo = s0 > a ? s0 : a, hi = e0 < b ? e0 : b;
       if (hi > lo) covered += hi - lo;
     }
-    u32 *d_count = c.d_scalars + 13;
-    HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream));
+    u32 *d_count = c.d_scalars + 34;
+    HIP_CHECK(hipMemsetAsync(d_count, 0, 2 * sizeof(u32), c.stream));
     hipLaunchKernelGGL(k_count_symbol, dim3(1024), dim3(256), 0, c.stream, c.T, (u64)a, (u64)b, rp.sym, d_count);
     HIP_CHECK(hipGetLastError());
     const i64 outside = (i64)read_u32(c, d_count) - covered;
     rp.merge = outside * 512 < b - a;
+  } else if (!rp.on && fits && c.max_sym < 16 && (u64)(b - a) >= c.bucket_min_n) {
+    // no long runs, but maybe a symbol that hardly occurs (a few N scattered over a genome): the rarest one
+    u32 *d_counts = c.d_scalars + 48;
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, 16 * sizeof(u32), c.stream));
+    hipLaunchKernelGGL(k_count_symbols16, dim3(1024), dim3(256), 0, c.stream, c.T, (u64)a, (u64)b, d_counts);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 48, d_counts, 16 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    int rare = 0;
+    for (int v = c.min_sym + 1; v <= c.max_sym; v++)
+      if (rare == 0 || c.h_scalars[48 + v] < c.h_scalars[48 + rare]) rare = v;
+    if (rare && (u64)c.h_scalars[48 + rare] * 512 < (u64)(b - a)) {
+      rp.on = true;
+      rp.sym = (u32)rare;
+      rp.merge = true;
+    }
   }
   return rp;
 }
@@ -2603,8 +2731,8 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   if (N < c.bucket_min_n || N < 2 || N >= (1ull << 32) - 8) return 0;
   // a largest symbol that shares the code of the one below it (RunPlan::merge): the keys' alphabet is one smaller
   // (only where the alphabet without it has 2^k symbols: bit-field codes)
-  const bool merged = rp && rp->on && rp->merge && !shard && e == b && span >= 2 && rp->sym == min_sym + (u32)span &&
-                      ((u32)span & (u32)(span - 1)) == 0;
+  const bool merged = rp && rp->on && rp->merge && !shard && e == b && span >= 2 && rp->sym > min_sym && rp->sym <= min_sym + (u32)span &&
+                      ((u32)span & (u32)(span - 1)) == 0 && c.max_sym < 128;
   if (merged) span--;
   const bool pow2 = ((u32)(span + 1) & (u32)span) == 0;  // 2^k symbols: zero-based codes save a bit (TextKeys)
   // Alphabets of 3, 5, 6 or 7 symbols (DNA with N): the codes as digits of a number in that base, scaled to the top of
@@ -2630,7 +2758,9 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   // (2^19 buckets for windows of 2^31 suffixes and more: a 10-bit second digit)
   const u64 Nf = (u64)((double)N / fill);
   int bbits = 16;
-  while (bbits < 19 && (Nf >> bbits) > 8200) bbits++;
+  // (a symbol without a code of its own leaves the suffixes that hold it early with few distinct keys: those gather in
+  // a few buckets, which then need room)
+  while (bbits < 19 && (Nf >> bbits) > (merged ? 4100u : 8200u)) bbits++;
   if (c.wide_bbits >= 2 && c.wide_bbits <= 19) bbits = c.wide_bbits;
   if ((Nf >> bbits) > 8200) return 0;
   const int b2 = bbits > 18 ? 10 : (bbits > 16 ? 9 : (bbits + 1) / 2), b1 = bbits - b2;
@@ -2667,11 +2797,11 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   // run would do), enough that the keys left out fall inside one bucket.
   bool runf = rp && rp->on && !shard && e == b && rp->sym >= min_sym && (int)(rp->sym - min_sym) <= span + (merged ? 1 : 0);
   int kf = h16 > 7 ? h16 - 6 : 1;
-  if (merged) tk.code_max = (u32)(span + one_based);
+  if (merged) tk.code_max = 1;
   if (runf) {
     const u64 B = base ? base : 1ull << w, scl = base ? scale : 1ull << (56 - K0 * w);
     u64 code_c = rp->sym - min_sym + (u32)one_based;
-    if (merged) code_c = tk.code_max;
+    if (merged) code_c = rp->sym - min_sym - 1;  // (the code of the symbol below it; zero-based: 2^k symbols)
     const int kmax = lean_count_symbols(tk);  // what the counting pass sees of a key
     // (a symbol without a code of its own: every suffix that begins with it is left out -- their keys are all the
     // same -- and, the symbol being the largest, their block comes behind everything else)
@@ -2738,7 +2868,12 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
     rcur = radix_sort_u64(c, keys, vals, run_cnt, 0, 64);
     c.sort_tag = "";
     if (merged) {
-      HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d_run_at, (int)(u32)kept, 1, c.stream));
+      // every suffix that begins with the symbol is in the block: it comes behind the suffixes that begin with a smaller one
+      u32 *d_count = c.d_scalars + 34;
+      HIP_CHECK(hipMemsetAsync(d_count, 0, 2 * sizeof(u32), c.stream));
+      hipLaunchKernelGGL(k_count_symbol, dim3(1024), dim3(256), 0, c.stream, c.T, (u64)a, (u64)b, rp->sym, d_count);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(d_run_at, d_count + 1, sizeof(u32), hipMemcpyDeviceToDevice, c.stream));
     } else {
       hipLaunchKernelGGL(k_run_block_start, dim3(1), dim3(256), 0, c.stream, (const u64 *)el[cur].get(), (const u32 *)bs.start.get(),
                          (u32)(tk.run_lo >> (64 - bbits)), tk, (u32)((1ull << pbits) - 1ull), rp->sym, (u32)kf, d_run_at);
@@ -2776,6 +2911,15 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
     em.n_runs = c.n_runs;
   }
   HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
+  // buckets with too many equal keys for the bucket kernel are listed and taken by a general one afterwards
+  DBuf<u32> deferred;
+  u32 *d_deferred = c.d_scalars + 36;
+  if (e == b && c.defer_buckets) {
+    deferred = DBuf<u32>(c, n_buckets);
+    HIP_CHECK(hipMemsetAsync(d_deferred, 0, sizeof(u32), c.stream));
+    em.defer_list = deferred.get();
+    em.defer_count = d_deferred;
+  }
   {
     KernelTimer kt(c, "leaf:k_bucket_emit", (double)N * 8 + (double)(b - a));
     if (e == b) {
@@ -2789,6 +2933,15 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
     }
   }
   if (read_u32(c, d_fail) != 0) return 0;
+  if (em.defer_list) {
+    const u32 n_def = read_u32(c, d_deferred);
+    if (n_def > 0) {
+      KernelTimer kt(c, "leaf:k_bucket_general", (double)n_def * bs.max_bucket * 8);
+      hipLaunchKernelGGL(k_bucket_general, dim3(n_def), dim3(BG_THREADS), 0, c.stream, em, (const u32 *)bs.start.get(), (const u32 *)deferred.get());
+      HIP_CHECK(hipGetLastError());
+      if (read_u32(c, d_fail) != 0) return 0;
+    }
+  }
   if (runf && run_cnt > 0) {
     // the sorted suffixes behind the block move up by its length, then the block takes its ranks
     Phase ph(c, "leaf_run_block", (double)kept * 2 + (double)run_cnt * 16);

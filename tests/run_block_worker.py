@@ -61,6 +61,30 @@ def main():
     T[13500], T[75000], T[128200], T[209000], T[276000] = 1, 3, 4, 1, 3
     check(T, 4, n, 30000, 1)
     check(T, 4, 75000, 30000, None)
+    # the run symbol in the middle of the alphabet and rare outside its runs (no code of its own: the symbols above it
+    # are coded one lower), as digits and as letters (A C G N T: the device holds them renumbered 1 .. 5, N = 4)
+    T = with_runs(n, 52, 5, 4, [(7000, 9000), (60000, 22000), (150000, 8192), (280000, 15000)])
+    body = T[:-1]
+    keep4 = np.zeros(len(body), dtype=bool)
+    for at, length in [(7000, 9000), (60000, 22000), (150000, 8192), (280000, 15000)]:
+        keep4[at:at + length] = True
+    scattered = (body == 4) & ~keep4
+    body[scattered] = np.where(np.random.default_rng(9).random(int(scattered.sum())) < 0.002, 4, 5).astype(np.uint8)
+    check(T, 5, n, 2500, 1)
+    check(T, 5, n // 3, 2500, None)
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[1:6] = [65, 67, 71, 78, 84]
+    check(lut[T], 84, n, 2500, 1)
+    check(lut[T], 84, 110000, 300, None)
+    # no long runs at all, but a symbol that hardly occurs: every suffix that begins with it goes the same way
+    T = gen_text(n, 53, 4)
+    T[:-1][T[:-1] == 4] = 5
+    where = np.random.default_rng(10).integers(0, n - 1, size=150)
+    T[where] = 4
+    T[where[:40] + 1] = 4  # some of them in pairs
+    T[-1] = 0
+    check(T, 5, n, 900, 1)
+    check(lut[T], 84, n // 2, 900, 2)
     # letters (large byte values), bytes, three symbols
     T = with_runs(n, 47, 4, 3, [(100000, 40000)])
     T[:-1] += ord("a") - 1

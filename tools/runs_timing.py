@@ -25,6 +25,12 @@ def main():
         where = int(rng.integers(0, n - length - 1))
         T[where:where + length] = 5
     T[-1] = 0
+    if os.environ.get("RUNS_ASCII"):  # the same as letters, N between G and T, and some N scattered outside the runs
+        lut = np.zeros(256, dtype=np.uint8)
+        lut[1:6] = [65, 67, 71, 84, 78]
+        T = lut[T]
+        T[rng.integers(0, n - 1, size=int(os.environ["RUNS_ASCII"]))] = 78
+        T[-1] = 0
     ctx = bwt_amd.Context(0)
     ctx.set_text(T)
     ctx.set_timing(2)
