@@ -36,6 +36,13 @@ def main():
                 T[at + length:at + length + 8] = lo
         if rng.random() < 0.2:
             T[n - int(rng.integers(8200, 20000)):] = sym  # a run that ends the text
+        if rng.random() < 0.3:  # the run symbol also scattered outside its runs, or (no runs kept) only scattered
+            if rng.random() < 0.3:
+                T = rng.integers(lo, lo + sigma, size=n, dtype=np.int64).astype(np.uint8)
+                T[T == sym] = lo
+            T[rng.integers(0, n - 1, size=int(rng.integers(1, 400)))] = sym
+        if rng.random() < 0.3 and int(T.max()) < 120:  # symbols scattered over the byte range: held renumbered
+            T = (T.astype(np.int64) * 2 + int(rng.integers(0, 10))).astype(np.uint8)
         T[-1] = 0
         leaves = int(rng.integers(1, 4))
         th = -(-n // leaves)

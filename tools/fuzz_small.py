@@ -29,13 +29,20 @@ def make(rng):
     else:
         body = np.where(rng.random(n - 1) < 0.9, 0, rng.integers(0, sigma, size=n - 1))
     T = np.concatenate([(body + base).astype(np.uint8), np.zeros(1, dtype=np.uint8)])
+    top = base + sigma - 1
+    if sigma <= 64 and rng.random() < 0.25:  # the symbols scattered over the byte range (the device holds such a text renumbered)
+        values = np.sort(rng.choice(np.arange(1, 256), size=sigma, replace=False))
+        lut = np.zeros(256, dtype=np.uint8)
+        lut[base:base + sigma] = values
+        T = lut[T]
+        top = int(values[-1])
     th = int(rng.choice([n, max(1, n // 2), max(1, n // 3 + 1), max(1, n // 7), int(rng.integers(1, n + 1))]))
     ns = int(rng.choice([2, 3, 17, max(2, n // 10), n]))
     seg = int(rng.choice([0, 1, 5, 64, 1000]))
     if n > 3000:  # the oracle looks every chain head up through the sampled suffix array: keep that cheap
         seg = max(seg, 64) if seg else 0
         ns = max(ns, n // 50)
-    return T, base + sigma - 1, th, ns, seg, kind
+    return T, top, th, ns, seg, kind
 
 
 def main():
