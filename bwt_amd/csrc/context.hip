@@ -39,7 +39,8 @@ static size_t round_size(size_t b) {
 // Sized for the largest call bwt_hip_dist_merge_slice_noalloc accepts, whatever the left block's length: 4 Mi right
 // symbols (16 MiB for the sort's second buffer) next to a left block of 2^30 to 2^31 suffixes, whose grouping has the most
 // buckets (2^18 + 1 bounds, 1 MiB) and the most tiles (512 counters for each of 512 + 513 tiles, 3 MiB), plus the tile
-// map and the scan's partial sums (a few KiB): 20.1 MiB.
+// map and the scan's partial sums (a few KiB), and the merge's chunk bounds (a word per 4096 output symbols: 2 MiB for a
+// slice of 2^31 left symbols): 22.2 MiB.
 constexpr size_t SCRATCH_BYTES = (size_t)24 << 20;
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
