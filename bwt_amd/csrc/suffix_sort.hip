@@ -1278,16 +1278,14 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
     if constexpr (STAGE_L) E.direct_tied(win, (u64)s + idx, sb, lsym + lead, (u64)s, soft);
     else E.direct_tied(win, (u64)s + idx, sb, nullptr, 0, soft);
   }
-  if (!SLACK && E.defer_list) {
-    lds_barrier();
-    if (soft_s) {  // (what the bucket has written so far is written again, the same or right, by k_bucket_general)
-      if (tid == 0) E.defer_list[atomicAdd(E.defer_count, 1u)] = blockIdx.x;
-      return;
-    }
+  const bool may_defer = !SLACK && E.defer_list;
+  if (may_defer || (STAGE_L && E.L)) lds_barrier();  // (one barrier for both: the tied suffixes' flag and their bytes of L)
+  if (may_defer && soft_s) {  // (what the bucket has written so far is written again, the same or right, by k_bucket_general)
+    if (tid == 0) E.defer_list[atomicAdd(E.defer_count, 1u)] = blockIdx.x;
+    return;
   }
   if constexpr (STAGE_L) {
     if (!E.L) return;
-    lds_barrier();
     u8 *g0 = E.L + s - lead;  // 16-byte aligned
     const u32 end = lead + cnt;
     for (u32 t = tid; t * 16 < end; t += BK_THREADS) {
