@@ -303,7 +303,7 @@ void symbol_presence(Ctx &c, const u8 *dT, i64 n, u32 present[8]) {
 }
 
 // (src and dst 16-byte aligned)
-__global__ void __launch_bounds__(256) k_map_symbols(const u8 *__restrict__ src, u8 *__restrict__ dst, u64 n, const u8 *__restrict__ table) {
+__global__ void __launch_bounds__(256) k_map_symbols(const u8 *src, u8 *dst, u64 n, const u8 *__restrict__ table) {
   __shared__ u8 tab[256];
   tab[threadIdx.x] = table[threadIdx.x];
   __syncthreads();
