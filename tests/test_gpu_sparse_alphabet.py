@@ -133,3 +133,9 @@ def test_switched_off_gives_the_same(tmp_path):
             "assert (b.L == ob.L).all() and b.e_char == ob.e_char; print('same')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BWT_HIP_COMPACT="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "same" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_text_in_the_callers_device_memory():
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "text_device_worker.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "text device ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
