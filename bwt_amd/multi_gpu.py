@@ -196,12 +196,25 @@ def host_to_host_native(ctx, transport, n, th, ns, seg, steps, dist, dev):
     import numpy as np
     import torch
     import bwt_amd
-    Th = bwt_amd.HostBuffer(n)
-    ctx.read_text(Th.a)
     s = ctx.dist_pmbwt(transport, th, ns, seg)
     size, nsamp = s.size, s.n_samples
     s.free()
-    Lh, Sr, Sp = bwt_amd.HostBuffer(max(1, size)), bwt_amd.HostBuffer(8 * max(1, nsamp)), bwt_amd.HostBuffer(8 * max(1, nsamp))
+    # the page-locked buffers come first, and every rank hears whether all ranks got theirs: the builds below are
+    # collective, a rank that dropped out would leave the others waiting
+    bufs, why = [], None
+    try:
+        for nbytes in (n, max(1, size), 8 * max(1, nsamp), 8 * max(1, nsamp)):
+            bufs.append(bwt_amd.HostBuffer(nbytes))
+    except Exception as e:
+        why = repr(e)
+    got = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(got, op=dist.ReduceOp.MIN)
+    if not int(got.item()):
+        for b in bufs:
+            b.close()
+        return {"value": None, "skipped": why or "another rank could not allocate its page-locked buffers"}
+    Th, Lh, Sr, Sp = bufs
+    ctx.read_text(Th.a)
     sr, sp = Sr.a.view(np.int64), Sp.a.view(np.int64)
     ok = True
 

@@ -16,14 +16,16 @@ def main():
     run = int(float(sys.argv[2])) if len(sys.argv) > 2 else 30000000
     leaves = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     rng = np.random.default_rng(5)
-    T = rng.integers(1, 5, size=n, dtype=np.uint8)
+    sigma = int(os.environ.get("RUNS_SIGMA", "4"))  # symbols of the random part
+    sym = int(os.environ.get("RUNS_SYM", str(sigma + 1)))  # the run symbol (default: one more, behind the alphabet)
+    T = rng.integers(1, sigma + 1, size=n, dtype=np.uint8)
     at = n // 2 - run // 3  # the run crosses the middle of the text
-    T[at:at + run] = 5
+    T[at:at + run] = sym
     more = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # further runs of the same symbol, 1e4 symbols up to `run`, anywhere
     for _ in range(more):
         length = int(10 ** rng.uniform(4, np.log10(run)))
         where = int(rng.integers(0, n - length - 1))
-        T[where:where + length] = 5
+        T[where:where + length] = sym
     T[-1] = 0
     if os.environ.get("RUNS_ASCII"):  # the same as letters, N between G and T, and some N scattered outside the runs
         lut = np.zeros(256, dtype=np.uint8)
