@@ -89,6 +89,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_FORCE_WIDE")) c.force_wide = atoi(v);
   if (const char *v = getenv("BWT_HIP_WIDE_BBITS")) c.wide_bbits = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_ANY")) c.lean_any_order = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_LEAN_SLOTS")) c.lean_slots = atoi(v);
   if (const char *v = getenv("BWT_HIP_GAP_LEAN")) c.gap_lean = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_HOST_PACK")) c.host_pack = atoi(v);
   if (const char *v = getenv("BWT_HIP_XFER_CHUNK")) c.xfer_chunk = atoll(v);

@@ -126,6 +126,9 @@ struct Ctx {
   int force_wide = 0;
   int wide_bbits = 0;
   bool lean_any_order = true;
+  int lean_slots = 1;  // the lean route's second pass reserves its output by atomic adds (no histogram of its digits);
+                       // tests: 3: also where the slots cost far more memory than the elements (small texts), 2: with too
+                       // few slots, so that the pass is void and the one with exact offsets follows
   bool lean_base = true;  // alphabets of 3, 5, 6, 7 symbols: lean keys as numbers in that base (off: such windows are sorted as pairs)
   bool gap_lean = true;  // the gap histogram's grouping in two passes that keep neither digit (gap_sort_lean)
   // chains whose head does not come out of a short backward search are finished by a second launch that searches
@@ -349,6 +352,7 @@ struct BucketState {
   int begin_bit = 0;
   int bbits = 16;      // a bucket = the elements that share their top bbits key bits
   u32 max_bucket = 0;  // elements of the largest bucket
+  u32 slot = 0;        // lean elements only; not 0: bucket k's elements lie from k * slot on (start[] still holds its ranks)
   bool pending = false;
 };
 int leaf_sort_text_packed(Ctx &c, u64 *elems[2], size_t n, int begin_bit, const TextKeys &text, BucketState *bs,

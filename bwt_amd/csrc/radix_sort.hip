@@ -299,7 +299,8 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 const u8 *sd = nullptr, u8 *side_s = nullptr,
                                                 u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
                                                 u32 lean_tile0 = 0, u32 narrow_mask = 0, u32 keep_lo = 0, u32 keep_hi = 0,
-                                                u32 dropm = 0) {
+                                                u32 dropm = 0, u32 *__restrict__ cursor = nullptr, u32 cell0 = 0, u32 slot = 0,
+                                                u32 *__restrict__ over = nullptr) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -317,6 +318,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
   if constexpr (ANY_ORDER) {
     u32 *all = cnt[0];  // one row of counters for the whole tile
     if (tid < (u32)DIG) all[tid] = 0;
+    if (cursor && tid == 0) scan_s[16] = 0;  // (never together with filt, which keeps the tile's count there)
     lds_barrier();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -338,11 +340,27 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
     if (tid < (u32)DIG) {
       const u32 ds = incl - tot;
       dstart[tid] = REVERSE ? ds + tot - 1 : ds;
-      gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
+      if (cursor) {
+        // No table of offsets: digit d of this tile's region owns the `slot` elements from (cell0 + d) * slot on, and the
+        // tile takes its place among them with one atomic add on the digit's fill count.
+        u32 g = 0;
+        if (tot) {
+          const u32 old = atomicAdd(&cursor[cell0 + tid], tot);
+          if (old + tot > slot) scan_s[16] = 1;
+          g = (cell0 + tid) * slot + old - ds;
+        }
+        gbase[tid] = g;
+      } else {
+        gbase[tid] = offs[(size_t)tid * nblk + (REVERSE ? nblk - 1 - tile : tile)] - ds;
+      }
     }
     if (filt && tid == (u32)DIG - 1) scan_s[16] = incl;  // what the tile keeps
     lds_barrier();
     if (filt) tile_kept = scan_s[16];
+    if (cursor && scan_s[16]) {  // a digit's elements do not fit its slots: the tile writes nothing, the pass is void
+      if (tid == 0) *over = 1;
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) rk[r] = REVERSE ? dstart[dig[r]] - rk[r] : dstart[dig[r]] + rk[r];
   } else {
@@ -457,7 +475,9 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     k_rs_scatter(const K *__restrict__ kin, const u32 *__restrict__ vin, K *__restrict__ kout,
                  u32 *__restrict__ vout, size_t n, int shift, u32 mask, const u32 *__restrict__ offs,
                  u32 nblk, TextKeys tk, u32 stride, const u8 *__restrict__ side_in = nullptr,
-                 u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr, u32 narrow_mask = 0) {
+                 u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr, u32 narrow_mask = 0,
+                 u32 *__restrict__ cursor = nullptr, u32 slot = 0, const u32 *__restrict__ treg = nullptr,
+                 u32 *__restrict__ over = nullptr) {
   static_assert(!SIDE || (sizeof(K) == 8 && !HAS_VALS && !SPLIT), "side bytes go with 8-byte keys-only elements");
   u8 sd[RS_ITEMS];
   static_assert(!SPLIT || sizeof(K) == 8, "only 64-bit keys are split");
@@ -585,14 +605,15 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     }
   }
   const u32 lean_posmask = (TEXT && tk.lean) ? (u32)((1ull << tk.pbits) - 1ull) : 0u;
+  const u32 cell0 = cursor ? treg[tile] << DB : 0u;  // slots instead of offsets: the tile's region, times the digits
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm);
+                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm);
+                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -1019,7 +1040,8 @@ int leaf_sort_text_wide(Ctx &c, u64 *elems[2], u8 *sides[2], size_t n, int bbits
 // those from keep_hi on empty at n.
 __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ offs1, u32 nblk, u32 nd1, u32 n,
                                                      u32 *__restrict__ tfirst, uint2 *__restrict__ tmap, u32 nblk2,
-                                                     u32 *__restrict__ rstart = nullptr, u32 keep_lo = 0, u32 keep_hi = ~0u) {
+                                                     u32 *__restrict__ rstart = nullptr, u32 keep_lo = 0, u32 keep_hi = ~0u,
+                                                     u32 *__restrict__ treg = nullptr) {
   __shared__ u32 rs[513], tf[513];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
@@ -1037,6 +1059,7 @@ __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ off
   for (u32 t = tid; t < nblk2; t += 1024) {
     if (t >= total) {
       tmap[t] = make_uint2(n, 0u);
+      if (treg) treg[t] = 0;
       continue;
     }
     u32 lo = 0, hi = nd1;  // the last region d with tf[d] <= t (empty regions share their tf with the next one)
@@ -1048,6 +1071,7 @@ __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ off
     const u32 t0 = rs[lo] + (t - tf[lo]) * RS_TILE;
     const u32 left = rs[lo + 1] - t0;
     tmap[t] = make_uint2(t0, left < (u32)RS_TILE ? left : (u32)RS_TILE);
+    if (treg) treg[t] = lo;  // the region the tile lies in
   }
 }
 
@@ -1215,6 +1239,22 @@ static void lean_second_pass(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk
   HIP_CHECK(hipGetLastError());
 }
 
+// The second pass with a fixed number of output elements per bucket (slot) instead of scanned offsets: no histogram,
+// no scan; fill[region << DB | digit] counts what the bucket holds, *over is raised when one of them outgrows its slots.
+template <int DB>
+static void lean_second_pass_slots(Ctx &c, const u64 *in, u64 *out, size_t n, u32 nblk2, const TextKeys &tk, const uint2 *tmap,
+                                   const u32 *treg, u32 *fill, u32 slot, u32 *over) {
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  const int shift = 64 - tk.b2;
+  const u32 mask = (1u << tk.b2) - 1u;
+  KernelTimer kt(c, "leaf:k_rs_scatter_u64_keys", (double)n * 16);
+  hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, false, false, true, false, DB>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream, in,
+                     (const u32 *)nullptr, out, (u32 *)nullptr, n, shift, mask, (const u32 *)nullptr, nblk2, none, 0u, (const u8 *)nullptr,
+                     (u8 *)nullptr, tmap, 0u, fill, slot, treg, over);
+  HIP_CHECK(hipGetLastError());
+}
+
 // The gap histogram's sort with the same device (gap.hip): 32-bit values grouped by their bits [low, low + b1 + b2).
 // The first pass sorts on the lower b1 of those bits, the second on the upper b2 over tiles that follow the first
 // pass's regions; neither needs a stable order (the buckets are only counted), and the second writes just the low
@@ -1366,10 +1406,22 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   }
   if (kept_out) *kept_out = kept;
   const size_t room = kept > 0 ? kept : 1;
-  elems[0] = DBuf<u64>(c, room);
+  // The second pass without its histogram: every bucket owns `slot` elements of the output, a tile reserves its
+  // place in a bucket with one atomic add per digit, and what the buckets hold falls out of the fill counts.  For the
+  // even texts this route is made for a bucket stays within eight standard deviations of the mean; one that does
+  // not voids the pass, and the pass with exact offsets runs instead.
+  u32 slot = 0;
+  if (c.lean_slots && c.lean_any_order && !(shard && shard->parts > 1) && !text.run_span && kept == n) {
+    const double avg = (double)n / (double)n_buckets;
+    u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
+    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
+    if (s <= cap && (u64)n_buckets * s < (1ull << 32) - (1ull << 20) &&
+        (c.lean_slots > 1 || (double)n_buckets * (double)s <= 1.25 * (double)n + 65536.0))
+      slot = (u32)s;
+  }
   elems[1] = DBuf<u64>(c, room);
   DBuf<u8> digits;
-  if (text.b2 <= 8) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
+  if (text.b2 <= 8 && !slot) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
     digits = DBuf<u8>(c, room + 16);
     first.next_digits = digits.get();
     first.next_shift = 64 - text.b2;
@@ -1379,16 +1431,54 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   // the second pass's tiles: those of what was kept, cut at the regions' ends (at most one short tile per region)
   const u32 nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
   DBuf<uint2> tmap(c, nblk2);
+  DBuf<u32> treg;
+  if (slot) treg = DBuf<u32>(c, nblk2);
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
-                     tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi);
+                     tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi, slot ? treg.get() : (u32 *)nullptr);
   HIP_CHECK(hipGetLastError());
+  u32 *d_max = c.d_scalars + 12;
+  if (slot) {
+    u32 *d_over = c.d_scalars + 37;
+    elems[0] = DBuf<u64>(c, (size_t)n_buckets * slot);
+    DBuf<u32> fill(c, (size_t)n_buckets + 1);
+    HIP_CHECK(hipMemsetAsync(fill.get(), 0, ((size_t)n_buckets + 1) * sizeof(u32), c.stream));
+    HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(u32), c.stream));
+    HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
+    if (text.b2 > 9) lean_second_pass_slots<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, tmap.get(), treg.get(), fill.get(), slot, d_over);
+    else if (text.b2 > 8) lean_second_pass_slots<9>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, tmap.get(), treg.get(), fill.get(), slot, d_over);
+    else lean_second_pass_slots<8>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, tmap.get(), treg.get(), fill.get(), slot, d_over);
+    // bucket k = region << b2 | digit is cell k of the fill counts; its first rank: the counts below it
+    bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
+    {
+      KernelTimer kt(c, "leaf:k_bucket_bounds", (double)n_buckets * 12);
+      scan_exclusive_u32(c, fill.get(), bs->start.get(), (size_t)n_buckets + 1, nullptr);
+      hipLaunchKernelGGL(k_bucket_max, dim3(n_buckets / 256), dim3(256), 0, c.stream, bs->start.get(), d_max, n_buckets);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_scalars + 1, d_over, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    if (!c.h_scalars[1]) {
+      bs->max_bucket = c.h_scalars[0];
+      if (bs->max_bucket > cap) {
+        bs->start = DBuf<u32>();
+        return -1;
+      }
+      bs->begin_bit = 0;
+      bs->bbits = bbits;
+      bs->slot = slot;
+      bs->pending = true;
+      return 0;
+    }
+    slot = 0;  // some bucket outgrew its slots: the same pass with exact offsets
+  }
+  elems[0] = DBuf<u64>(c, room);
   DBuf<u32> counts2(c, (size_t)(text.b2 > 9 ? 1024 : (text.b2 > 8 ? 512 : 256)) * nblk2);
   if (text.b2 > 9) lean_second_pass<10>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
   else if (text.b2 > 8) lean_second_pass<9>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), nullptr, tfirst.get(), rstart.get());
   else lean_second_pass<8>(c, elems[1].get(), elems[0].get(), kept, nblk2, text, counts2.get(), tmap.get(), digits.get(), tfirst.get(), rstart.get());
   counts = std::move(counts2);
   bs->start = DBuf<u32>(c, (size_t)n_buckets + 1);
-  u32 *d_max = c.d_scalars + 12;
   {
     KernelTimer kt(c, "leaf:k_bucket_bounds", (double)n_buckets * 12);
     HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
@@ -1406,6 +1496,7 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   }
   bs->begin_bit = 0;
   bs->bbits = bbits;
+  bs->slot = 0;
   bs->pending = true;
   return 0;
 }

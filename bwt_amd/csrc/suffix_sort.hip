@@ -93,6 +93,7 @@ struct PackedView {
   int pbits;
   static constexpr bool WIDE = false;
   // what the bucket kernel needs of an element (sd: its side byte, none in this layout)
+  __device__ __forceinline__ const u64 *bucket_elems(u32, u32 first_rank) const { return e + first_rank; }
   __device__ __forceinline__ u32 bucket_key(u64 x, u32) const { return (u32)(x >> 32) & 0xFFFFu; }  // the 16 key bits below the bucket's
   __device__ __forceinline__ u32 elem_pos(u64 x) const { return a + ((u32)x & posmask); }
   __device__ __forceinline__ u32 elem_prev(u64 x, u32) const { return ((u32)x >> pbits) & 0xFFu; }
@@ -133,6 +134,7 @@ struct WideView {
   const u8 *side;  // | key bits 31..28 | preceding symbol |
   int kshift;      // 20 - bbits: the 16 key bits below the bucket's start this far up in the 36-bit key
   static constexpr bool WIDE = true;
+  __device__ __forceinline__ const u64 *bucket_elems(u32, u32 first_rank) const { return e + first_rank; }
   __device__ __forceinline__ u32 bucket_key(u64 x, u32 sd) const {
     return (u32)((((x >> 32) << 4) | (sd >> 4)) >> kshift) & 0xFFFFu;
   }
@@ -148,7 +150,9 @@ struct LeanView {
   const u64 *e;
   u32 a, posmask, vmask;
   int pbits, b2, xbits;
+  u32 slot;  // not 0: bucket k's elements lie from k * slot on, whatever its first rank
   static constexpr bool WIDE = false;
+  __device__ __forceinline__ const u64 *bucket_elems(u32 k, u32 first_rank) const { return slot ? e + (size_t)k * slot : e + first_rank; }
   __device__ __forceinline__ u32 bucket_key(u64 x, u32) const { return (u32)((x << b2) >> 48); }
   __device__ __forceinline__ u32 elem_pos(u64 x) const { return a + ((u32)x & posmask); }
   __device__ __forceinline__ u32 elem_prev(u64 x, u32) const { return (u32)(x >> pbits) & vmask; }
@@ -1110,7 +1114,7 @@ __global__ void __launch_bounds__(BK_THREADS, 8)  // two workgroups per CU
   const u32 lead = STAGE_L ? (u32)(reinterpret_cast<uintptr_t>(E.L + s) & 15) : 0u;
   const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 wbase = w * (64 * ITEMS);
-  const u64 *mine = E.v.e + s;
+  const u64 *mine = E.v.bucket_elems(blockIdx.x, s);
   const u8 *mine_side = nullptr;
   if constexpr (WIDE) mine_side = E.v.side + s;
   {
@@ -1314,7 +1318,8 @@ __global__ void __launch_bounds__(BG_THREADS) k_bucket_general(LeafEmit<LeanView
   const u32 tid = threadIdx.x;
   u32 n2 = 2;
   while (n2 < cnt) n2 <<= 1;
-  for (u32 i = tid; i < n2; i += BG_THREADS) buf[i] = i < cnt ? E.v.e[s + i] : ~0ull;  // (all ones: no element; they end up last)
+  const u64 *mine = E.v.bucket_elems(b, s);
+  for (u32 i = tid; i < n2; i += BG_THREADS) buf[i] = i < cnt ? mine[i] : ~0ull;  // (all ones: no element; they end up last)
   __syncthreads();
   auto less = [&](u64 x, u64 y) -> bool {
     if (x == ~0ull || y == ~0ull) return x != ~0ull && y == ~0ull;
@@ -2895,7 +2900,7 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   }
   if (em.L) em.L -= first_rank;
   em.sa_out = sa_out ? res.get() - first_rank : nullptr;
-  em.v = LeanView{el[cur].get() - first_rank, (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16};
+  em.v = LeanView{el[cur].get() - first_rank, (u32)a, (u32)((1ull << pbits) - 1ull), (1u << vbits) - 1u, pbits, b2, deep - 16, bs.slot};
   em.N = first_rank + kept;  // (ranks: a share's elements begin at its first rank)
   em.sym_mask = ~0xFFull;  // BucketWindow<LeanView>::key: the ordered key bits above the preceding symbol
   em.samp_ratio = em.m > 1 ? (double)(em.ns - 1) / (double)(i64)(em.m - 1) : 1.0;

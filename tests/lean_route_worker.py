@@ -26,6 +26,17 @@ def main():
     for th in (len(T), 150000, 40000):
         same_as_oracle(ctx, T, 4, th, 3000)
     assert lean_launches(ctx) >= 1 + 2 + 8, sorted(ctx.timers())
+    # the second pass: offsets from a histogram of its digits, or slots reserved as it goes (BWT_HIP_LEAN_SLOTS)
+    t = ctx.timers()
+    hists = sum(v[2] for k, v in t.items() if k in ("leaf:k_rs_hist_u64", "leaf:k_rs_hist_bytes"))
+    passes = t["leaf:k_rs_scatter_u64_keys"][2]
+    mode = os.environ.get("BWT_HIP_LEAN_SLOTS", "1")
+    if mode == "3":
+        assert hists == 0 and passes >= 11, (hists, passes)
+    elif mode == "2":  # every pass void, then again with offsets
+        assert hists >= 11 and passes == 2 * hists, (hists, passes)
+    else:  # small texts: the slots would cost far more memory than the elements
+        assert hists == passes >= 11, (hists, passes)
     # the text ends in a run of the smallest symbol: equal keys that ran into the terminator
     T = gen_text(200000, 7, 4)
     T[-3000:-1] = 1
