@@ -90,6 +90,10 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_WIDE_BBITS")) c.wide_bbits = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_ANY")) c.lean_any_order = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_LEAN_SLOTS")) c.lean_slots = atoi(v);
+  if (const char *v = getenv("BWT_HIP_SLOT_SUB")) {
+    const int k = atoi(v);
+    c.slot_sub = (u32)(k < 1 ? 1 : (k > 16 ? 16 : k));
+  }
   if (const char *v = getenv("BWT_HIP_GAP_LEAN")) c.gap_lean = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_HOST_PACK")) c.host_pack = atoi(v);
   if (const char *v = getenv("BWT_HIP_XFER_CHUNK")) c.xfer_chunk = atoll(v);

@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(GH_THREADS)
 // The same from the two-pass grouping that keeps neither digit (gap_sort_lean): a bucket's values are the 16-bit
 // words [start[bucket], start[bucket + 1]), each the low bits of a g whose high bits are the bucket's number.
 __global__ void __launch_bounds__(GH_THREADS)
-    k_bucket_prefix16(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 *__restrict__ S) {
+    k_bucket_prefix16(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 *__restrict__ S, u32 slot) {
   __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x;
@@ -418,14 +418,16 @@ __global__ void __launch_bounds__(GH_THREADS)
   const u32 bucket = blockIdx.x;
   for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
   __syncthreads();
-  const u32 lo = start[bucket], hi = start[bucket + 1];
+  const u32 lo = start[bucket], cnt = start[bucket + 1] - lo;
   const u64 base = (u64)bucket << low;
-  for (u32 i0 = lo + tid; i0 < hi; i0 += 8 * GH_THREADS) {
+  // (slot: the bucket's words lie from bucket * slot on, not behind those of the buckets below it)
+  const u16 *words = keys + (slot ? (size_t)bucket * slot : (size_t)lo);
+  for (u32 i0 = tid; i0 < cnt; i0 += 8 * GH_THREADS) {
     u32 g[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       u32 i = i0 + k * GH_THREADS;
-      g[k] = i < hi ? (u32)keys[i] : 0xFFFFFFFFu;
+      g[k] = i < cnt ? (u32)words[i] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -786,10 +788,11 @@ void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S) {
     const int b2 = (high + 1) / 2, b1 = high - b2;
     Phase ph(c, "gap_histogram", (double)total * (12 + 10 + 2) + (double)(m + 1) * 4);
     DBuf<u32> start(c, ((size_t)1 << high) + 1);
-    gap_sort_lean(c, keys, total, low, b1, b2, start.get());
+    u32 slot = 0;
+    gap_sort_lean(c, keys, total, low, b1, b2, start.get(), &slot, n_buckets);
     KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 2 + (double)(m + 1) * 4);
     hipLaunchKernelGGL(k_bucket_prefix16, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, reinterpret_cast<const u16 *>(keys[0]),
-                       (const u32 *)start.get(), low, (u32)m, S);
+                       (const u32 *)start.get(), low, (u32)m, S, slot);
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -126,6 +126,7 @@ struct Ctx {
   int force_wide = 0;
   int wide_bbits = 0;
   bool lean_any_order = true;
+  u32 slot_sub = 8;    // areas per first digit where a first pass reserves its output that way (1 to 16; 8: one per XCD)
   int lean_slots = 1;  // the lean route's second pass reserves its output by atomic adds (no histogram of its digits);
                        // tests: 3: also where the slots cost far more memory than the elements (small texts), 2: with too
                        // few slots, so that the pass is void and the one with exact offsets follows
@@ -381,7 +382,10 @@ int radix_sort_u32(Ctx &c, u32 *keys[2], u32 *vals[2], size_t n, int begin_bit, 
 // The gap histogram's grouping: the values of keys[0] grouped by their bits [low, low + b1 + b2), in two passes
 // that keep neither digit; afterwards keys[0] holds the values' low `low` bits as 16-bit words, bucket k of them
 // at [start[k], start[k+1]) (start: 2^(b1+b2) + 1 entries).
-void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start);
+// slot_out (may be null): the caller can read buckets that are not contiguous; *slot_out != 0 then says that bucket k's
+// words lie from k * *slot_out on, and start[k] is only the number of values in the buckets below k.  used_buckets: how
+// many of the 2^(b1+b2) buckets the values can fall into (0: all), for the size of a slot.
+void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start, u32 *slot_out = nullptr, u32 used_buckets = 0);
 
 // ---------------------------------------------------------------------------
 // a partial BWT resident on the device (include/bwt.h:122-149 of the reference)

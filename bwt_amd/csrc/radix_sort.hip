@@ -300,7 +300,7 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
                                                 u8 *__restrict__ side_out = nullptr, u32 lean_posmask = 0,
                                                 u32 lean_tile0 = 0, u32 narrow_mask = 0, u32 keep_lo = 0, u32 keep_hi = 0,
                                                 u32 dropm = 0, u32 *__restrict__ cursor = nullptr, u32 cell0 = 0, u32 slot = 0,
-                                                u32 *__restrict__ over = nullptr) {
+                                                u32 *__restrict__ over = nullptr, u32 dmul = 1) {
   constexpr int DIG = 1 << DB;
   u32(*cnt)[DIG] = reinterpret_cast<u32(*)[DIG]>(buf);
   u32 *dstart = reinterpret_cast<u32 *>(buf) + RS_WAVES * DIG;
@@ -341,13 +341,14 @@ __device__ __forceinline__ void rs_scatter_tile(K (&key)[RS_ITEMS], u32 (&val)[R
       const u32 ds = incl - tot;
       dstart[tid] = REVERSE ? ds + tot - 1 : ds;
       if (cursor) {
-        // No table of offsets: digit d of this tile's region owns the `slot` elements from (cell0 + d) * slot on, and the
-        // tile takes its place among them with one atomic add on the digit's fill count.
+        // No table of offsets: digit d of this tile's region owns the `slot` elements from cell * slot on (cell =
+        // cell0 + d * dmul), and the tile takes its place among them with one atomic add on the cell's fill count.
         u32 g = 0;
         if (tot) {
-          const u32 old = atomicAdd(&cursor[cell0 + tid], tot);
+          const u32 cell = cell0 + tid * dmul;
+          const u32 old = atomicAdd(&cursor[cell], tot);
           if (old + tot > slot) scan_s[16] = 1;
-          g = (cell0 + tid) * slot + old - ds;
+          g = cell * slot + old - ds;
         }
         gbase[tid] = g;
       } else {
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
                  u32 nblk, TextKeys tk, u32 stride, const u8 *__restrict__ side_in = nullptr,
                  u8 *__restrict__ side_out = nullptr, const uint2 *__restrict__ tmap = nullptr, u32 narrow_mask = 0,
                  u32 *__restrict__ cursor = nullptr, u32 slot = 0, const u32 *__restrict__ treg = nullptr,
-                 u32 *__restrict__ over = nullptr) {
+                 u32 *__restrict__ over = nullptr, u32 dmul = 1) {
   static_assert(!SIDE || (sizeof(K) == 8 && !HAS_VALS && !SPLIT), "side bytes go with 8-byte keys-only elements");
   u8 sd[RS_ITEMS];
   static_assert(!SPLIT || sizeof(K) == 8, "only 64-bit keys are split");
@@ -605,15 +606,21 @@ __global__ void __launch_bounds__(RS_THREADS, (HAS_VALS && sizeof(K) == 8) ? 4 :
     }
   }
   const u32 lean_posmask = (TEXT && tk.lean) ? (u32)((1ull << tk.pbits) - 1ull) : 0u;
-  const u32 cell0 = cursor ? treg[tile] << DB : 0u;  // slots instead of offsets: the tile's region, times the digits
+  // Slots instead of offsets (cursor): cell = region * 2^DB + digit (dmul 1: the leaf sort, region-major), or
+  // digit * dmul + region (the gap grouping: its second digit is the more significant one); no regions: cell = digit.
+  // A pass over plain tiles (no treg): cell = digit * dmul + workgroup mod dmul, dmul areas per digit.  With eight
+  // areas that is an area per XCD (workgroups go round the XCDs): the runs that neighbour each other in an area then
+  // come from one XCD, whose L2 joins them into whole lines before they leave for memory -- with the areas taken by
+  // tile number instead, neighbouring runs come from different L2s and the pass takes 5.3 ms instead of 3.7.
+  const u32 cell0 = !cursor ? 0u : (treg ? (dmul == 1 ? treg[tile] << DB : treg[tile]) : blockIdx.x % dmul);
   if (full)
     rs_scatter_tile<K, HAS_VALS, true, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs, nblk,
                                               tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over);
+                                              lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over, dmul);
   else
     rs_scatter_tile<K, HAS_VALS, false, SPLIT, TEXT, ANY_ORDER, SIDE, DB>(key, val, buf, gbase, scan_s, kout, vout, tile_n, shift, mask, offs,
                                                nblk, tile, stride, TEXT ? tk.next_digits : nullptr, tk.next_shift, sd, side_s, side_out,
-                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over);
+                                               lean_posmask, (u32)tile0, narrow_mask, TEXT ? tk.keep_lo : 0u, TEXT ? tk.keep_hi : 0u, dropm, cursor, cell0, slot, over, dmul);
 }
 
 // tile histogram of digits that are already bytes (TextKeys::next_digits): 16 of them per thread
@@ -879,10 +886,22 @@ __global__ void k_max_u32(const u32 *__restrict__ v, u32 n, u32 *__restrict__ ou
 // A sample of the window (16 positions out of every 4096) says whether some bucket will be far too large
 // for a workgroup (twice its capacity: sampling noise must not turn an even text away); the two passes on
 // the top 16 bits are then not worth trying.
-static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n, int bbits = 16, u32 cap = BK_CAP) {
+// out[r] = sum of the `per` values of v from r * per on (one wave per r)
+__global__ void __launch_bounds__(64) k_group_sums(const u32 *__restrict__ v, u32 per, u32 *__restrict__ out) {
+  u32 sum = 0;
+  for (u32 k = threadIdx.x; k < per; k += 64) sum += v[(size_t)blockIdx.x * per + k];
+  sum = wave_reduce_sum(sum);
+  if (threadIdx.x == 0) out[blockIdx.x] = sum;
+}
+
+// regions (may be null): out, the sampled positions whose key's top `rbits` bits are r, for every r, and in
+// *sampled how many positions were sampled in all (left empty when there are too few samples).
+static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n, int bbits = 16, u32 cap = BK_CAP, std::vector<u64> *regions = nullptr,
+                              int rbits = 0, u64 *sampled = nullptr) {
   constexpr u64 STRIDE = 256;  // one position in 256
   const u32 n_buckets = 1u << bbits;
   const u64 count = n / (16 * STRIDE) * 16;
+  if (regions) regions->clear();
   if (count < 4 * (u64)n_buckets) return true;  // too few samples to say anything
   KernelTimer kt(c, "leaf:k_bucket_histogram", (double)count * 8);
   DBuf<u32> hist(c, n_buckets);
@@ -893,7 +912,21 @@ static bool buckets_look_even(Ctx &c, const TextKeys &tk, size_t n, int bbits = 
   hipLaunchKernelGGL(k_max_u32, dim3(n_buckets / 256), dim3(256), 0, c.stream, hist.get(), n_buckets, d_max);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_max, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  std::vector<u32> h;
+  DBuf<u32> sums;
+  if (regions) {
+    const u32 nr = 1u << rbits;
+    h.resize(nr);
+    sums = DBuf<u32>(c, nr);
+    hipLaunchKernelGGL(k_group_sums, dim3(nr), dim3(64), 0, c.stream, (const u32 *)hist.get(), n_buckets >> rbits, sums.get());
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(h.data(), sums.get(), (size_t)nr * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  }
   c.sync();
+  if (regions) {
+    regions->assign(h.begin(), h.end());
+    *sampled = count;
+  }
   return (u64)c.h_scalars[0] * STRIDE <= (u64)cap * 2;
 }
 
@@ -1075,6 +1108,63 @@ __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ off
   }
 }
 
+// The same after a first pass with slots instead of offsets: region d lies in `sub` areas of slot1 elements each, area
+// a = d * sub + j from a * slot1 on with fill1[a] of them in use (a workgroup of the first pass wrote into the areas
+// j = its number mod sub: see k_rs_scatter).  Tiles never cross an area; treg[t] = the region.
+constexpr u32 LT_AREAS = 8192;
+__global__ void __launch_bounds__(1024) k_lean_tiles_areas(const u32 *__restrict__ fill1, u32 nd1, u32 sub, u32 slot1,
+                                                           u32 *__restrict__ tfirst, uint2 *__restrict__ tmap,
+                                                           u32 *__restrict__ treg, u32 nblk2, u32 *__restrict__ rstart = nullptr) {
+  __shared__ u32 rl[LT_AREAS], tf[LT_AREAS + 1];
+  __shared__ u32 scan_s[17];
+  const u32 tid = threadIdx.x, na = nd1 * sub, per = (na + 1023) / 1024;
+  u32 mine = 0;
+  for (u32 k = 0; k < per; k++) {
+    const u32 a = tid * per + k;
+    if (a < na) {
+      const u32 len = fill1[a];
+      rl[a] = len;
+      tf[a] = mine;
+      mine += (len + RS_TILE - 1) / RS_TILE;
+    }
+  }
+  u32 total;
+  const u32 base = block_scan_incl<OpSum>(mine, scan_s, &total) - mine;
+  for (u32 k = 0; k < per; k++) {
+    const u32 a = tid * per + k;
+    if (a < na) tf[a] += base;
+  }
+  if (tid == 0) tf[na] = total;
+  __syncthreads();
+  for (u32 d = tid; d <= nd1; d += 1024) tfirst[d] = tf[d * sub];
+  if (rstart) {  // rstart[d] = elements of the regions below d: where region d begins once the elements lie densely
+    __syncthreads();  // (scan_s is used again)
+    u32 reg = 0;
+    if (tid < nd1)
+      for (u32 j = 0; j < sub; j++) reg += rl[tid * sub + j];
+    u32 all;
+    const u32 incl = block_scan_incl<OpSum>(reg, scan_s, &all);
+    if (tid < nd1) rstart[tid] = incl - reg;
+    if (tid == nd1) rstart[tid] = all;
+  }
+  for (u32 t = tid; t < nblk2; t += 1024) {
+    if (t >= total) {
+      tmap[t] = make_uint2(0u, 0u);
+      treg[t] = 0;
+      continue;
+    }
+    u32 lo = 0, hi = na;  // the last area a with tf[a] <= t (empty areas share their tf with the next one)
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) / 2;
+      if (tf[mid] <= t) lo = mid;
+      else hi = mid;
+    }
+    const u32 done = (t - tf[lo]) * RS_TILE, left = rl[lo] - done;
+    tmap[t] = make_uint2(lo * slot1 + done, left < (u32)RS_TILE ? left : (u32)RS_TILE);
+    treg[t] = lo / sub;
+  }
+}
+
 // start[d2 << b1 | d1] = first element of that bucket after the second pass: the scanned count of digit d2 at the
 // first tile of region d1 (the pass is stable and its tiles follow the regions in order); start[n_buckets] = n
 __global__ void k_lean_bucket_starts(const u32 *__restrict__ offs2, u32 nblk2, const u32 *__restrict__ tfirst, int b1,
@@ -1179,10 +1269,20 @@ static void lean_text_hist(Ctx &c, size_t n, u32 nblk, const TextKeys &tk, const
   HIP_CHECK(hipGetLastError());
 }
 
+// fill1 (may be null): no offsets (counts is not read): digit d's elements go to the `sub` areas of slot1 elements each
+// from (d * sub) * slot1 on, fill1[d * sub + j] counts what area j holds and *over is raised when one outgrows slot1.
 template <int DB>
-static void lean_text_scatter(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, u32 *counts) {
+static void lean_text_scatter(Ctx &c, u64 *out, size_t n, u32 nblk, const TextKeys &tk, u32 *counts, u32 *fill1 = nullptr, u32 slot1 = 0,
+                              u32 sub = 1, u32 *over = nullptr) {
   const u32 mask = (1u << tk.b1) - 1u;
   KernelTimer kt(c, "leaf:k_rs_scatter_text", (double)n * 9);
+  if (fill1) {
+    hipLaunchKernelGGL((k_rs_scatter<u64, false, 0, true, false, true, false, DB>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                       (const u64 *)nullptr, (const u32 *)nullptr, out, (u32 *)nullptr, n, 13, mask, (const u32 *)nullptr, nblk, tk, 0u,
+                       (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr, 0u, fill1, slot1, (const u32 *)nullptr, over, sub);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   // the staged elements carry the digit above the low 13 bits of their position field
   // (only the any-order ranking knows how to leave elements out)
   if (tk.run_span)
@@ -1260,6 +1360,84 @@ static void lean_second_pass_slots(Ctx &c, const u64 *in, u64 *out, size_t n, u3
 // pass's regions; neither needs a stable order (the buckets are only counted), and the second writes just the low
 // `low` bits of a value, as 16-bit words: bucket (d2, d1) = the words [start[d2 << b1 | d1], start[.. + 1]) of the
 // result, which is in keys[0] (keys[1] is scratch).  start: 2^(b1+b2) + 1 entries.
+static u32 read_flag(Ctx &c, const u32 *d) {
+  HIP_CHECK(hipMemcpyAsync(c.h_scalars, d, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  return c.h_scalars[0];
+}
+
+// The same with slots instead of offsets (see leaf_sort_text_lean): neither pass has a histogram.  The first pass
+// writes region d1 into the slot1 words from d1 * slot1 on of a buffer of its own, the second bucket k = d2 << b1 | d1
+// into the slot2 16-bit words from k * slot2 on of keys[0]; start[k] = values in the buckets below k.  Gap indices of
+// blocks that resemble each other spread evenly; where they do not, some cell outgrows its slots and the pass is
+// void: 0 then, with keys[0] as it was (the first pass), or 2 with the second pass done the other way (contiguous
+// buckets); 1: done, with slots.
+template <int DB1, int DB2>
+static int gap_sort_slots_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start, u32 slot2, u32 used_buckets) {
+  const u32 nblk = ceil_div(n, RS_TILE);
+  const u32 nd1 = 1u << b1, n_buckets = 1u << (b1 + b2);
+  // a first digit's share: the buckets that have it (one more for some digits when the buckets in use are not a
+  // multiple of the digits), and room for a few thousand filler values, which all fall into one bucket
+  // (every digit's values spread over `sub` areas, one per XCD)
+  const u32 sub = c.slot_sub, na = nd1 * sub;
+  const double avg1 = (double)n / (double)used_buckets * (double)ceil_div(used_buckets, nd1) / (double)sub;
+  const u32 slot1 = c.lean_slots == 4 ? (u32)avg1 + 1 : (u32)(((u64)(avg1 + 8.0 * sqrt(avg1) + 4096.0 + 64.0) + 63) & ~63ull);  // (4: tests)
+  const u32 nblk2 = ceil_div(n, RS_TILE) + na + 1;
+  DBuf<u32> mid(c, (size_t)na * slot1);
+  DBuf<u32> fill1(c, na), fill2(c, (size_t)n_buckets + 1), tfirst(c, nd1 + 1), treg(c, nblk2);
+  DBuf<uint2> tmap(c, nblk2);
+  u32 *d_over = c.d_scalars + 37;
+  TextKeys none;
+  memset(&none, 0, sizeof(none));
+  HIP_CHECK(hipMemsetAsync(fill1.get(), 0, na * sizeof(u32), c.stream));
+  HIP_CHECK(hipMemsetAsync(fill2.get(), 0, ((size_t)n_buckets + 1) * sizeof(u32), c.stream));
+  HIP_CHECK(hipMemsetAsync(d_over, 0, 2 * sizeof(u32), c.stream));
+  {
+    KernelTimer kt(c, "gap:k_rs_scatter_u32_slots", (double)n * 8);
+    hipLaunchKernelGGL((k_rs_scatter<u32, false, 2, false, false, true, false, DB1>), dim3(nblk), dim3(RS_THREADS), 0, c.stream,
+                       (const u32 *)keys[0], (const u32 *)nullptr, mid.get(), (u32 *)nullptr, n, low, nd1 - 1, (const u32 *)nullptr, nblk, none, 0u,
+                       (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr, 0u, fill1.get(), slot1, (const u32 *)nullptr, d_over, sub);
+    HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_lean_tiles_areas, dim3(1), dim3(1024), 0, c.stream, (const u32 *)fill1.get(), nd1, sub, slot1, tfirst.get(),
+                     tmap.get(), treg.get(), nblk2);
+  HIP_CHECK(hipGetLastError());
+  if (read_flag(c, d_over) != 0) return 0;  // the first pass is void: nothing has been written over
+  {
+    KernelTimer kt(c, "gap:k_rs_scatter_u32_slots2", (double)n * 6);
+    hipLaunchKernelGGL((k_rs_scatter<u32, false, 2, false, false, true, false, DB2>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream,
+                       (const u32 *)mid.get(), (const u32 *)nullptr, keys[0], (u32 *)nullptr, n, low + b1, (1u << b2) - 1u, (const u32 *)nullptr,
+                       nblk2, none, 0u, (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)tmap.get(), (1u << low) - 1u, fill2.get(), slot2,
+                       (const u32 *)treg.get(), d_over + 1, nd1);
+    HIP_CHECK(hipGetLastError());
+  }
+  scan_exclusive_u32(c, fill2.get(), start, (size_t)n_buckets + 1, nullptr);
+  if (read_flag(c, d_over + 1) != 0) {
+    // the second pass again, with exact offsets, from where the first one left the values
+    DBuf<u32> counts(c, (size_t)(1 << DB2) * nblk2);
+    {
+      KernelTimer kt(c, "gap:k_rs_hist_u32", (double)n * 4);
+      hipLaunchKernelGGL((k_rs_hist<u32, 2, false, DB2>), dim3(nblk2), dim3(RH_THREADS), 0, c.stream, (const u32 *)mid.get(), n, low + b1,
+                         (1u << b2) - 1u, counts.get(), nblk2, none, (const uint2 *)tmap.get());
+      HIP_CHECK(hipGetLastError());
+    }
+    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)(1 << DB2) * nblk2, nullptr);
+    {
+      KernelTimer kt(c, "gap:k_rs_scatter_u32_keys", (double)n * 6);
+      hipLaunchKernelGGL((k_rs_scatter<u32, false, 2, false, false, true, false, DB2>), dim3(nblk2), dim3(RS_THREADS), 0, c.stream,
+                         (const u32 *)mid.get(), (const u32 *)nullptr, keys[0], (u32 *)nullptr, n, low + b1, (1u << b2) - 1u, counts.get(),
+                         nblk2, none, 0u, (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)tmap.get(), (1u << low) - 1u);
+      HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_lean_bucket_starts, dim3(n_buckets / 256 + 1), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk2,
+                       (const u32 *)tfirst.get(), b1, n_buckets, (u32)n, start);
+    HIP_CHECK(hipGetLastError());
+    c.sync();  // (counts goes back to the pool)
+    return 2;
+  }
+  return 1;
+}
+
 template <int DB1, int DB2>
 static void gap_sort_lean_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start) {
   const u32 nblk = ceil_div(n, RS_TILE);
@@ -1306,9 +1484,28 @@ static void gap_sort_lean_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, 
   HIP_CHECK(hipGetLastError());
 }
 
-void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start) {
+void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 *start, u32 *slot_out, u32 used_buckets) {
   if (n == 0 || n >= (1ull << 32) || b1 < 1 || b1 > 9 || b2 < 1 || b2 > 9 || low < 1 || low > 16)
     fail(BWT_HIP_EINTERNAL, "gap sort: bad layout (n %zu, low %d, b1 %d, b2 %d)", n, low, b1, b2);
+  if (slot_out) *slot_out = 0;
+  if (slot_out && c.lean_slots && !c.arena_on) {  // (a call that may not allocate: the leaner of the two in memory)
+    // slots where they cost little more memory than the values: the second pass's 16-bit words fit keys[0]
+    const u32 n_buckets = 1u << (b1 + b2);
+    if (!used_buckets || used_buckets > n_buckets) used_buckets = n_buckets;
+    const double avg = (double)n / (double)used_buckets;
+    u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
+    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;
+    if (((u64)used_buckets + 1) * s * 2 <= (u64)n * 4 && s < 65536) {
+      int done;
+      if (b1 > 8 && b2 > 8) done = gap_sort_slots_impl<9, 9>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
+      else if (b2 > 8) done = gap_sort_slots_impl<8, 9>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
+      else done = gap_sort_slots_impl<8, 8>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
+      if (done) {
+        *slot_out = done == 1 ? (u32)s : 0u;
+        return;
+      }
+    }
+  }
   if (b1 > 8 && b2 > 8) gap_sort_lean_impl<9, 9>(c, keys, n, low, b1, b2, start);
   else if (b2 > 8) gap_sort_lean_impl<8, 9>(c, keys, n, low, b1, b2, start);
   else gap_sort_lean_impl<8, 8>(c, keys, n, low, b1, b2, start);
@@ -1331,21 +1528,88 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
       (text.base ? (bbits + text.lean_deep > 56 || text.K0 > 56) : (text.K0 * text.w < bbits + text.lean_deep || text.K0 * text.w > 56)))
     fail(BWT_HIP_EINTERNAL, "leaf sort: bad lean layout (b1 %d, b2 %d, deep %d, pbits %d, vbits %d, K0 %d, w %d, n %zu)", text.b1,
          text.b2, text.lean_deep, text.pbits, text.vbits, text.K0, text.w, n);
-  if (!buckets_look_even(c, text, n, bbits, cap)) return -1;
+  std::vector<u64> reg_est;
+  u64 sampled = 0;
+  if (!buckets_look_even(c, text, n, bbits, cap, &reg_est, text.b1, &sampled)) return -1;
   const u32 nblk = ceil_div(n, RS_TILE);
   const u32 nd1 = 1u << text.b1, n_buckets = 1u << bbits;
   TextKeys first = text;
   first.next_digits = nullptr;
   TextKeys count_keys = first;
   count_keys.K0 = lean_count_symbols(text);
-  DBuf<u32> counts(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
   DBuf<u32> tfirst(c, nd1 + 1), rstart(c, nd1 + 1);
-  if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
-  else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
   const u32 dig1 = text.b1 > 8 ? 512u : 256u;  // counter rows of the text pass
   size_t kept = n;
   u64 first_rank = 0;
   u32 scan_lo = 0, scan_hi = dig1;
+  // Slots instead of offsets, where the whole leaf is sorted here and nothing is left out.
+  // The second pass without its histogram: every bucket owns `slot` elements of the output, a tile reserves its
+  // place in a bucket with one atomic add per digit, and what the buckets hold falls out of the fill counts.  For the
+  // even texts this route is made for a bucket stays within eight standard deviations of the mean; one that does
+  // not voids the pass, and the pass with exact offsets runs instead.
+  // The first pass the same way, with the regions' sizes estimated from the sample above (eight areas per region,
+  // one per XCD: see k_rs_scatter); a region that outgrows the estimate voids it, and the counted pass runs.
+  const bool plain = !(shard && shard->parts > 1) && !text.run_span;
+  u32 slot = 0, slot1 = 0;
+  const u32 sub = c.slot_sub, na = nd1 * sub;
+  if (plain && c.lean_slots && !c.arena_on && c.lean_any_order) {
+    const double avg = (double)n / (double)n_buckets;
+    u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
+    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
+    if (s <= cap && (u64)n_buckets * s < (1ull << 32) - (1ull << 20) &&
+        (c.lean_slots > 1 || (double)n_buckets * (double)s <= 1.25 * (double)n + 65536.0))
+      slot = (u32)s;
+    double est = 0, rel = 0;  // the largest region, and how far the sample may be off (six standard deviations)
+    if (!reg_est.empty()) {
+      u64 k = 1;
+      for (u64 v : reg_est) k = v > k ? v : k;
+      est = (double)k * ((double)n / (double)sampled);
+      rel = 6.0 / sqrt((double)k);
+    } else if (c.lean_slots > 2) {  // (tests, on texts too small for a sample)
+      est = 2.0 * (double)n / (double)nd1 + 1024.0;
+    }
+    if (slot && est > 0) {
+      const double area = est / (double)sub;
+      u64 s1 = ((u64)(area * (1.0 + rel) + 8.0 * sqrt(area) + 64.0) + 63) & ~63ull;
+      if (c.lean_slots == 4) s1 = (u64)(area / 8) + 1;  // (tests: too small)
+      if ((u64)na * s1 < (1ull << 32) - (1ull << 20) && na <= LT_AREAS &&
+          (c.lean_slots > 2 || (double)na * (double)s1 <= 1.15 * (double)n + 1048576.0))
+        slot1 = (u32)s1;
+    }
+  }
+  bool first_done = false;
+  u32 nblk2 = 0;
+  DBuf<uint2> tmap;
+  DBuf<u32> treg;
+  DBuf<u32> counts;
+  u32 *d_over = c.d_scalars + 37;
+  if (slot1) {
+    elems[1] = DBuf<u64>(c, (size_t)na * slot1);
+    DBuf<u32> fill1(c, na);
+    HIP_CHECK(hipMemsetAsync(fill1.get(), 0, na * sizeof(u32), c.stream));
+    HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(u32), c.stream));
+    if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, nullptr, fill1.get(), slot1, sub, d_over);
+    else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, nullptr, fill1.get(), slot1, sub, d_over);
+    nblk2 = nblk + na + 1;
+    tmap = DBuf<uint2>(c, nblk2);
+    treg = DBuf<u32>(c, nblk2);
+    hipLaunchKernelGGL(k_lean_tiles_areas, dim3(1), dim3(1024), 0, c.stream, (const u32 *)fill1.get(), nd1, sub, slot1, tfirst.get(),
+                       tmap.get(), treg.get(), nblk2, rstart.get());
+    HIP_CHECK(hipGetLastError());
+    first_done = read_flag(c, d_over) == 0;  // (fill1 goes back to the pool after this)
+    if (first_done && shard) {
+      shard->first_rank = 0;
+      shard->count = n;
+      shard->bounds.assign(2, 0);
+      shard->bounds[1] = n;
+    }
+    if (!first_done) elems[1] = DBuf<u64>();
+  }
+  DBuf<u8> digits;
+  if (!first_done) {
+  counts = DBuf<u32>(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
+  if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
+  else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
   if (shard && shard->parts > 1) {
     // This GPU keeps a stretch of the first digit's values: the `part`-th of `parts` stretches that hold about the
     // same number of suffixes each.  Every GPU counts the whole text and cuts the same way; nothing is exchanged.
@@ -1404,23 +1668,8 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
     u32 *rows = counts.get() + (size_t)scan_lo * nblk;
     scan_exclusive_u32(c, rows, rows, (size_t)(scan_hi - scan_lo) * nblk, nullptr);
   }
-  if (kept_out) *kept_out = kept;
   const size_t room = kept > 0 ? kept : 1;
-  // The second pass without its histogram: every bucket owns `slot` elements of the output, a tile reserves its
-  // place in a bucket with one atomic add per digit, and what the buckets hold falls out of the fill counts.  For the
-  // even texts this route is made for a bucket stays within eight standard deviations of the mean; one that does
-  // not voids the pass, and the pass with exact offsets runs instead.
-  u32 slot = 0;
-  if (c.lean_slots && c.lean_any_order && !(shard && shard->parts > 1) && !text.run_span && kept == n) {
-    const double avg = (double)n / (double)n_buckets;
-    u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
-    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
-    if (s <= cap && (u64)n_buckets * s < (1ull << 32) - (1ull << 20) &&
-        (c.lean_slots > 1 || (double)n_buckets * (double)s <= 1.25 * (double)n + 65536.0))
-      slot = (u32)s;
-  }
   elems[1] = DBuf<u64>(c, room);
-  DBuf<u8> digits;
   if (text.b2 <= 8 && !slot) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
     digits = DBuf<u8>(c, room + 16);
     first.next_digits = digits.get();
@@ -1429,16 +1678,17 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, counts.get());
   else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, counts.get());
   // the second pass's tiles: those of what was kept, cut at the regions' ends (at most one short tile per region)
-  const u32 nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
-  DBuf<uint2> tmap(c, nblk2);
-  DBuf<u32> treg;
+  nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
+  tmap = DBuf<uint2>(c, nblk2);
   if (slot) treg = DBuf<u32>(c, nblk2);
   hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
                      tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi, slot ? treg.get() : (u32 *)nullptr);
   HIP_CHECK(hipGetLastError());
+  }
+  if (kept_out) *kept_out = kept;
+  const size_t room = kept > 0 ? kept : 1;
   u32 *d_max = c.d_scalars + 12;
   if (slot) {
-    u32 *d_over = c.d_scalars + 37;
     elems[0] = DBuf<u64>(c, (size_t)n_buckets * slot);
     DBuf<u32> fill(c, (size_t)n_buckets + 1);
     HIP_CHECK(hipMemsetAsync(fill.get(), 0, ((size_t)n_buckets + 1) * sizeof(u32), c.stream));

@@ -30,13 +30,17 @@ def main():
     t = ctx.timers()
     hists = sum(v[2] for k, v in t.items() if k in ("leaf:k_rs_hist_u64", "leaf:k_rs_hist_bytes"))
     passes = t["leaf:k_rs_scatter_u64_keys"][2]
+    firsts = t["leaf:k_rs_scatter_text"][2]
+    counted = t.get("leaf:k_rs_hist_text", (0, 0, 0))[2]  # first passes that counted their digits beforehand
     mode = os.environ.get("BWT_HIP_LEAN_SLOTS", "1")
     if mode == "3":
-        assert hists == 0 and passes >= 11, (hists, passes)
-    elif mode == "2":  # every pass void, then again with offsets
-        assert hists >= 11 and passes == 2 * hists, (hists, passes)
+        assert hists == 0 and passes >= 11 and counted == 0 and firsts == passes, (hists, passes, counted, firsts)
+    elif mode == "2":  # every second pass void, then again with offsets (first passes: counted, the texts are too small for a sample)
+        assert hists >= 11 and passes == 2 * hists and counted == hists, (hists, passes, counted)
+    elif mode == "4":  # every first pass void, then again after counting
+        assert hists == 0 and counted == passes >= 11 and firsts == 2 * passes, (hists, passes, counted, firsts)
     else:  # small texts: the slots would cost far more memory than the elements
-        assert hists == passes >= 11, (hists, passes)
+        assert hists == passes == counted >= 11, (hists, passes, counted)
     # the text ends in a run of the smallest symbol: equal keys that ran into the terminator
     T = gen_text(200000, 7, 4)
     T[-3000:-1] = 1

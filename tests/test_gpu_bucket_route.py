@@ -28,12 +28,12 @@ def test_wide_bucket_route_on_small_texts():
     assert "wide route ok" in r.stdout
 
 
-@pytest.mark.parametrize("slots", ["1", "3", "2"])
+@pytest.mark.parametrize("slots", ["1", "3", "2", "4"])
 def test_lean_bucket_route_on_small_texts(slots):
     """The route of windows between 2^29 and 2^31 suffixes (8-byte elements without the first pass's digit, two
     passes, 2^16 to 2^18 buckets), forced onto small texts.  slots: the second pass as it chooses itself (offsets
     from a histogram on small texts, a fixed number of slots per bucket on large ones), with slots on every text, and
-    with too few slots (the pass notices, and runs again with offsets)."""
+    with too few slots in the second pass or in the first (the pass notices, and runs again with offsets)."""
     env = dict(os.environ, BWT_HIP_BUCKET_MIN_N="1", BWT_HIP_FORCE_WIDE="2", BWT_HIP_LEAN_SLOTS=slots)
     r = subprocess.run([sys.executable, os.path.join(HERE, "lean_route_worker.py")], env=env, capture_output=True,
                        text=True, timeout=300)
