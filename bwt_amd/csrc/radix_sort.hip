@@ -1112,20 +1112,19 @@ __global__ void __launch_bounds__(1024) k_lean_tiles(const u32 *__restrict__ off
 // a = d * sub + j from a * slot1 on with fill1[a] of them in use (a workgroup of the first pass wrote into the areas
 // j = its number mod sub: see k_rs_scatter).  Tiles never cross an area; treg[t] = the region.
 constexpr u32 LT_AREAS = 8192;
-__global__ void __launch_bounds__(1024) k_lean_tiles_areas(const u32 *__restrict__ fill1, u32 nd1, u32 sub, u32 slot1,
-                                                           u32 *__restrict__ tfirst, uint2 *__restrict__ tmap,
-                                                           u32 *__restrict__ treg, u32 nblk2, u32 *__restrict__ rstart = nullptr) {
-  __shared__ u32 rl[LT_AREAS], tf[LT_AREAS + 1];
+// tfa[a] = tiles in the areas below a (na + 1 entries), tfirst[d] = tiles in the regions below d, and (rstart not null)
+// rstart[d] = elements of the regions below d: where region d begins once the elements lie densely.  One workgroup.
+__global__ void __launch_bounds__(1024) k_lean_areas_scan(const u32 *__restrict__ fill1, u32 nd1, u32 sub, u32 *__restrict__ tfa,
+                                                          u32 *__restrict__ tfirst, u32 *__restrict__ rstart) {
+  __shared__ u32 tf[LT_AREAS + 1];
   __shared__ u32 scan_s[17];
   const u32 tid = threadIdx.x, na = nd1 * sub, per = (na + 1023) / 1024;
   u32 mine = 0;
   for (u32 k = 0; k < per; k++) {
     const u32 a = tid * per + k;
     if (a < na) {
-      const u32 len = fill1[a];
-      rl[a] = len;
       tf[a] = mine;
-      mine += (len + RS_TILE - 1) / RS_TILE;
+      mine += (fill1[a] + RS_TILE - 1) / RS_TILE;
     }
   }
   u32 total;
@@ -1136,33 +1135,46 @@ __global__ void __launch_bounds__(1024) k_lean_tiles_areas(const u32 *__restrict
   }
   if (tid == 0) tf[na] = total;
   __syncthreads();
+  for (u32 a = tid; a <= na; a += 1024) tfa[a] = tf[a];
   for (u32 d = tid; d <= nd1; d += 1024) tfirst[d] = tf[d * sub];
-  if (rstart) {  // rstart[d] = elements of the regions below d: where region d begins once the elements lie densely
+  if (rstart) {
     __syncthreads();  // (scan_s is used again)
     u32 reg = 0;
     if (tid < nd1)
-      for (u32 j = 0; j < sub; j++) reg += rl[tid * sub + j];
+      for (u32 j = 0; j < sub; j++) reg += fill1[tid * sub + j];
     u32 all;
     const u32 incl = block_scan_incl<OpSum>(reg, scan_s, &all);
     if (tid < nd1) rstart[tid] = incl - reg;
     if (tid == nd1) rstart[tid] = all;
   }
-  for (u32 t = tid; t < nblk2; t += 1024) {
-    if (t >= total) {
+}
+
+// The tiles themselves: workgroup a < na cuts area a; the last one marks the tiles behind the last area as empty.
+__global__ void __launch_bounds__(64) k_lean_areas_map(const u32 *__restrict__ fill1, const u32 *__restrict__ tfa, u32 na, u32 sub,
+                                                       u32 slot1, uint2 *__restrict__ tmap, u32 *__restrict__ treg, u32 nblk2) {
+  const u32 a = blockIdx.x;
+  if (a == na) {
+    for (u32 t = tfa[na] + threadIdx.x; t < nblk2; t += 64) {
       tmap[t] = make_uint2(0u, 0u);
       treg[t] = 0;
-      continue;
     }
-    u32 lo = 0, hi = na;  // the last area a with tf[a] <= t (empty areas share their tf with the next one)
-    while (hi - lo > 1) {
-      const u32 mid = (lo + hi) / 2;
-      if (tf[mid] <= t) lo = mid;
-      else hi = mid;
-    }
-    const u32 done = (t - tf[lo]) * RS_TILE, left = rl[lo] - done;
-    tmap[t] = make_uint2(lo * slot1 + done, left < (u32)RS_TILE ? left : (u32)RS_TILE);
-    treg[t] = lo / sub;
+    return;
   }
+  const u32 t0 = tfa[a], t1 = tfa[a + 1], len = fill1[a];
+  for (u32 t = t0 + threadIdx.x; t < t1; t += 64) {
+    const u32 done = (t - t0) * RS_TILE, left = len - done;
+    tmap[t] = make_uint2(a * slot1 + done, left < (u32)RS_TILE ? left : (u32)RS_TILE);
+    treg[t] = a / sub;
+  }
+}
+
+static void lean_tiles_areas(Ctx &c, const u32 *fill1, u32 nd1, u32 sub, u32 slot1, u32 *tfirst, uint2 *tmap, u32 *treg, u32 nblk2,
+                             u32 *rstart) {
+  const u32 na = nd1 * sub;
+  DBuf<u32> tfa(c, (size_t)na + 1);
+  hipLaunchKernelGGL(k_lean_areas_scan, dim3(1), dim3(1024), 0, c.stream, fill1, nd1, sub, tfa.get(), tfirst, rstart);
+  hipLaunchKernelGGL(k_lean_areas_map, dim3(na + 1), dim3(64), 0, c.stream, fill1, (const u32 *)tfa.get(), na, sub, slot1, tmap, treg, nblk2);
+  HIP_CHECK(hipGetLastError());
 }
 
 // start[d2 << b1 | d1] = first element of that bucket after the second pass: the scanned count of digit d2 at the
@@ -1399,9 +1411,7 @@ static int gap_sort_slots_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, 
                        (const u8 *)nullptr, (u8 *)nullptr, (const uint2 *)nullptr, 0u, fill1.get(), slot1, (const u32 *)nullptr, d_over, sub);
     HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_lean_tiles_areas, dim3(1), dim3(1024), 0, c.stream, (const u32 *)fill1.get(), nd1, sub, slot1, tfirst.get(),
-                     tmap.get(), treg.get(), nblk2);
-  HIP_CHECK(hipGetLastError());
+  lean_tiles_areas(c, fill1.get(), nd1, sub, slot1, tfirst.get(), tmap.get(), treg.get(), nblk2, nullptr);
   if (read_flag(c, d_over) != 0) return 0;  // the first pass is void: nothing has been written over
   {
     KernelTimer kt(c, "gap:k_rs_scatter_u32_slots2", (double)n * 6);
@@ -1593,9 +1603,7 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
     nblk2 = nblk + na + 1;
     tmap = DBuf<uint2>(c, nblk2);
     treg = DBuf<u32>(c, nblk2);
-    hipLaunchKernelGGL(k_lean_tiles_areas, dim3(1), dim3(1024), 0, c.stream, (const u32 *)fill1.get(), nd1, sub, slot1, tfirst.get(),
-                       tmap.get(), treg.get(), nblk2, rstart.get());
-    HIP_CHECK(hipGetLastError());
+    lean_tiles_areas(c, fill1.get(), nd1, sub, slot1, tfirst.get(), tmap.get(), treg.get(), nblk2, rstart.get());
     first_done = read_flag(c, d_over) == 0;  // (fill1 goes back to the pool after this)
     if (first_done && shard) {
       shard->first_rank = 0;
