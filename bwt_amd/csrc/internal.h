@@ -338,6 +338,10 @@ struct TextKeys {
   // code -- "that symbol, then nothing larger" -- which keeps the keys in the order of the suffixes; equal keys then
   // need not be equal symbols.
   u32 run_sym, run_k, code_max;
+  // lean: the part of the buckets that the keys of an even text reach (0: all).  Keys as numbers in a base: the buckets
+  // below that part of the key space, evenly; bit-field codes that leave code values unused: unevenly.
+  float fill;
+  int fill_even;
 };
 int radix_sort_u64(Ctx &c, u64 *keys[2], u32 *vals[2], size_t n, int begin_bit, int end_bit);
 // Round 0 of the leaf suffix sort: sorts the (key, position) pairs of `text` on key bits [begin_bit, 64).

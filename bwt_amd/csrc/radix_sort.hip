@@ -1562,12 +1562,15 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   const bool plain = !(shard && shard->parts > 1) && !text.run_span;
   u32 slot = 0, slot1 = 0;
   const u32 sub = c.slot_sub, na = nd1 * sub;
-  if (plain && c.lean_slots && !c.arena_on && c.lean_any_order) {
-    const double avg = (double)n / (double)n_buckets;
+  // (only where the keys of an even text fill the buckets they reach evenly: all of them, or the lower part that keys
+  // as numbers in a base reach; bit-field codes with unused values fill them by a pattern of their own)
+  const double reach = text.fill > 0 ? (double)text.fill : 1.0;
+  if (plain && c.lean_slots && !c.arena_on && c.lean_any_order && (text.fill_even || reach > 0.97 || text.fill == 0)) {
+    const double avg = (double)n / ((double)n_buckets * reach);
     u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
     if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
     if (s <= cap && (u64)n_buckets * s < (1ull << 32) - (1ull << 20) &&
-        (c.lean_slots > 1 || (double)n_buckets * (double)s <= 1.25 * (double)n + 65536.0))
+        (c.lean_slots > 1 || (double)n_buckets * (double)s * reach <= 1.25 * (double)n + 65536.0))
       slot = (u32)s;
     double est = 0, rel = 0;  // the largest region, and how far the sample may be off (six standard deviations)
     if (!reg_est.empty()) {

@@ -2794,6 +2794,8 @@ static int try_lean_route(Ctx &c, i64 a, i64 b, i64 e, u64 N, u32 min_sym, int s
   tk.base = base;
   tk.scale = scale;
   tk.lead = lead;
+  tk.fill = (float)(base ? fill : (one_based ? pow((double)(span + 1) / (double)(1u << w), (double)bbits / (double)w) : 1.0));
+  tk.fill_even = base || !one_based;
   // long runs of one symbol: the suffixes that begin with kf copies of it stay out of the sort (RunPlan)
   // How many copies, kf: few enough that a suffix with kf - 1 of them still shows some symbols of what follows the
   // run in the 16 key bits its bucket is ordered on (the bucket kernel gives up on 16 equal values: one such suffix per
