@@ -407,22 +407,73 @@ __global__ void __launch_bounds__(GH_THREADS)
     if (base + j <= m) S[base + j] = hist[gh_slot(j)];
 }
 
-// The same from the two-pass grouping that keeps neither digit (gap_sort_lean): a bucket's values are the 16-bit
-// words [start[bucket], start[bucket + 1]), each the low bits of a g whose high bits are the bucket's number.
+// Heavy buckets.  The suffixes of a long run of one symbol in the right block can all fall into one gap of the left
+// block: a bucket then holds millions of values, which its one workgroup below would count for milliseconds.  The
+// (at most GH_HEAVY_MAX) buckets of more than GH_HEAVY_MIN values are listed, counted by GH_HEAVY_PARTS workgroups each
+// into counters in memory, and the bucket's own workgroup starts from those.
+constexpr u32 GH_HEAVY_MIN = 1u << 17, GH_HEAVY_MAX = 64, GH_HEAVY_PARTS = 128;
+
+// heavy[0] = how many (may exceed GH_HEAVY_MAX: the ones beyond are not listed), heavy[1 + i] = bucket
+__global__ void k_gap_heavy_list(const u32 *__restrict__ start, u32 n_buckets, u32 *__restrict__ heavy) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets || start[b + 1] - start[b] <= GH_HEAVY_MIN) return;
+  const u32 i = atomicAdd(&heavy[0], 1u);
+  if (i < GH_HEAVY_MAX) heavy[1 + i] = b;
+}
+
+// counts[i << low | v] += the values v of part blockIdx.x of heavy bucket i = blockIdx.y (counts: zeroed by the caller)
 __global__ void __launch_bounds__(GH_THREADS)
-    k_bucket_prefix16(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 *__restrict__ S, u32 slot) {
+    k_gap_heavy_count(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 slot,
+                      const u32 *__restrict__ heavy, u32 *__restrict__ counts) {
   __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
-  __shared__ u32 scan_s[17];
-  const u32 tid = threadIdx.x;
-  const u32 width = 1u << low;
-  const u32 bucket = blockIdx.x;
+  const u32 n_heavy = heavy[0] < GH_HEAVY_MAX ? heavy[0] : GH_HEAVY_MAX;
+  if (blockIdx.y >= n_heavy) return;
+  const u32 tid = threadIdx.x, width = 1u << low, bucket = heavy[1 + blockIdx.y];
   for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
   __syncthreads();
   const u32 lo = start[bucket], cnt = start[bucket + 1] - lo;
   const u64 base = (u64)bucket << low;
+  const u16 *words = keys + (slot ? (size_t)bucket * slot : (size_t)lo);
+  const u32 per = (cnt + GH_HEAVY_PARTS - 1) / GH_HEAVY_PARTS;
+  const u32 i_lo = blockIdx.x * per, i_hi = i_lo + per < cnt ? i_lo + per : cnt;
+  for (u32 i = i_lo + tid; i < i_hi; i += GH_THREADS) {
+    const u32 g = words[i];
+    if (base + g <= m) atomicAdd(&hist[gh_slot(g)], 1u);
+  }
+  __syncthreads();
+  for (u32 j = tid; j < width; j += GH_THREADS) {
+    const u32 v = hist[gh_slot(j)];
+    if (v) atomicAdd(&counts[((size_t)blockIdx.y << low) + j], v);
+  }
+}
+
+// The same from the two-pass grouping that keeps neither digit (gap_sort_lean): a bucket's values are the 16-bit
+// words [start[bucket], start[bucket + 1]), each the low bits of a g whose high bits are the bucket's number.
+// heavy, heavy_counts: the buckets already counted (k_gap_heavy_count).
+__global__ void __launch_bounds__(GH_THREADS)
+    k_bucket_prefix16(const u16 *__restrict__ keys, const u32 *__restrict__ start, int low, u32 m, u32 *__restrict__ S, u32 slot,
+                      const u32 *__restrict__ heavy, const u32 *__restrict__ heavy_counts) {
+  __shared__ u32 hist[(1 << GH_LOW_MAX) + (1 << (GH_LOW_MAX - 5))];
+  __shared__ u32 scan_s[17];
+  __shared__ u32 heavy_at;
+  const u32 tid = threadIdx.x;
+  const u32 width = 1u << low;
+  const u32 bucket = blockIdx.x;
+  if (tid == 0) heavy_at = ~0u;
+  for (u32 i = tid; i < width + (width >> 5); i += GH_THREADS) hist[i] = 0;
+  __syncthreads();
+  const u32 lo = start[bucket], cnt = start[bucket + 1] - lo;
+  const u64 base = (u64)bucket << low;
+  if (cnt > GH_HEAVY_MIN && heavy) {  // (the same for the whole workgroup)
+    const u32 n_heavy = heavy[0] < GH_HEAVY_MAX ? heavy[0] : GH_HEAVY_MAX;
+    if (tid < n_heavy && heavy[1 + tid] == bucket) heavy_at = tid;
+    __syncthreads();
+    if (heavy_at != ~0u)
+      for (u32 j = tid; j < width; j += GH_THREADS) hist[gh_slot(j)] = heavy_counts[((size_t)heavy_at << low) + j];
+  }
   // (slot: the bucket's words lie from bucket * slot on, not behind those of the buckets below it)
   const u16 *words = keys + (slot ? (size_t)bucket * slot : (size_t)lo);
-  for (u32 i0 = tid; i0 < cnt; i0 += 8 * GH_THREADS) {
+  for (u32 i0 = tid; i0 < (heavy_at != ~0u ? 0u : cnt); i0 += 8 * GH_THREADS) {
     u32 g[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -791,8 +842,19 @@ void gap_prefix(Ctx &c, u32 *g0, u32 *g1, u64 total, u64 m, u32 *S) {
     u32 slot = 0;
     gap_sort_lean(c, keys, total, low, b1, b2, start.get(), &slot, n_buckets);
     KernelTimer kt(c, "gap:k_bucket_prefix", (double)total * 2 + (double)(m + 1) * 4);
+    DBuf<u32> heavy, heavy_counts;
+    if (!c.arena_on) {  // (not in the call that may not allocate: 2 MB of counters)
+      heavy = DBuf<u32>(c, 1 + GH_HEAVY_MAX);
+      heavy_counts = DBuf<u32>(c, (size_t)GH_HEAVY_MAX << low);
+      HIP_CHECK(hipMemsetAsync(heavy.get(), 0, sizeof(u32), c.stream));
+      HIP_CHECK(hipMemsetAsync(heavy_counts.get(), 0, ((size_t)GH_HEAVY_MAX << low) * sizeof(u32), c.stream));
+      hipLaunchKernelGGL(k_gap_heavy_list, dim3(ceil_div(n_buckets, 256)), dim3(256), 0, c.stream, (const u32 *)start.get(), n_buckets, heavy.get());
+      hipLaunchKernelGGL(k_gap_heavy_count, dim3(GH_HEAVY_PARTS, GH_HEAVY_MAX), dim3(GH_THREADS), 0, c.stream,
+                         reinterpret_cast<const u16 *>(keys[0]), (const u32 *)start.get(), low, (u32)m, slot, (const u32 *)heavy.get(),
+                         heavy_counts.get());
+    }
     hipLaunchKernelGGL(k_bucket_prefix16, dim3(n_buckets), dim3(GH_THREADS), 0, c.stream, reinterpret_cast<const u16 *>(keys[0]),
-                       (const u32 *)start.get(), low, (u32)m, S, slot);
+                       (const u32 *)start.get(), low, (u32)m, S, slot, (const u32 *)heavy.get(), (const u32 *)heavy_counts.get());
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -239,3 +239,21 @@ def test_long_repeats_of_a_short_unit_across_block_boundaries(ctx, unit):
     T[-1] = 0
     _same_as_oracle(ctx, T, 4, 20000, 300, 64)
     _same_as_oracle(ctx, T, 4, 10000, 300)
+
+
+def test_run_across_the_leaf_boundary_fills_one_gap(ctx):
+    """A run of one symbol that crosses the boundary of two leaves: all suffixes of its right-hand part fall into ONE gap
+    of the left block (the left part's suffixes hold longer runs), so one bucket of the gap histogram holds millions
+    of values and is counted by many workgroups.  The merged L must be the L of the same text built as one leaf."""
+    n = 30000000
+    rng = np.random.default_rng(11)
+    T = rng.integers(1, 5, size=n, dtype=np.uint8)
+    T[n // 2 - 3000000:n // 2 + 6000000] = 5
+    T[-1] = 0
+    ctx.set_text(T)
+    one = ctx.pmbwt(n, 1000)
+    L1, s1 = one.L.copy(), one.s_rank
+    one.free()
+    two = ctx.pmbwt(n // 2 + 1, 1000)
+    assert two.s_rank == s1 and (two.L == L1).all() and two.ibwt_mismatches() == 0
+    two.free()
