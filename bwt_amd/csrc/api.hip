@@ -384,9 +384,11 @@ int bwt_hip_leaf_capacity(bwt_hip_ctx *ctx, int64_t n, int64_t *max_leaf) {
   HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
   // what the pool already holds from the driver is free to a build as well
   const double avail = 0.9 * ((double)free_b + (double)c.bytes_reserved - (double)c.bytes_live);
-  // measured peaks: 18.6 bytes per symbol for one leaf of the whole text, 10.3 for two leaves and their merge
-  const double leaf = (avail - 3.0 * (double)n) / 17.0;
-  *max_leaf = avail < 10.5 * (double)n || leaf < 1 ? 0 : (leaf > (double)n ? n : (int64_t)leaf);
+  // measured peaks (tools/leaf_memory.py, 3.1e9 symbols of DNA): 19.6 bytes per symbol for one leaf of the whole text
+  // (its two element buffers are 6 and 12 % larger than the elements: radix_sort.hip, slots), 11.1 for two leaves
+  // and their merge, 10.5 for eight leaves (the top merge)
+  const double leaf = (avail - 3.0 * (double)n) / 18.5;
+  *max_leaf = avail < 10.7 * (double)n || leaf < 1 ? 0 : (leaf > (double)n ? n : (int64_t)leaf);
   API_END
 }
 
