@@ -1578,6 +1578,9 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
       for (u64 v : reg_est) k = v > k ? v : k;
       est = (double)k * ((double)n / (double)sampled);
       rel = 6.0 / sqrt((double)k);
+      // A largest region well above the mean (symbols of unequal frequency) says the buckets are as uneven: their
+      // slots would overflow and the second pass be run twice.  Offsets, then.
+      if (c.lean_slots == 1 && est > (1.0 + rel + 0.03) * (double)n / ((double)nd1 * reach)) slot = 0;
     } else if (c.lean_slots > 2) {  // (tests, on texts too small for a sample)
       est = 2.0 * (double)n / (double)nd1 + 1024.0;
     }
