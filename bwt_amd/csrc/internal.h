@@ -129,7 +129,8 @@ struct Ctx {
   u32 slot_sub = 8;    // areas per first digit where a first pass reserves its output that way (1 to 16; 8: one per XCD)
   int lean_slots = 1;  // the lean route's second pass reserves its output by atomic adds (no histogram of its digits);
                        // tests: 3: also where the slots cost far more memory than the elements (small texts), 2: with too
-                       // few slots, so that the pass is void and the one with exact offsets follows
+                       // few slots in the second passes, so that they are void and the ones with exact offsets follow,
+                       // 4: the same for the first passes, 5: 3 and 2 together
   bool lean_base = true;  // alphabets of 3, 5, 6, 7 symbols: lean keys as numbers in that base (off: such windows are sorted as pairs)
   bool gap_lean = true;  // the gap histogram's grouping in two passes that keep neither digit (gap_sort_lean)
   // chains whose head does not come out of a short backward search are finished by a second launch that searches

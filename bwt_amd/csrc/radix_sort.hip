@@ -1504,7 +1504,7 @@ void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 
     if (!used_buckets || used_buckets > n_buckets) used_buckets = n_buckets;
     const double avg = (double)n / (double)used_buckets;
     u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
-    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;
+    if (c.lean_slots == 2 || c.lean_slots == 5) s = avg < 1.0 ? 1 : (u64)avg;
     if (((u64)used_buckets + 1) * s * 2 <= (u64)n * 4 && s < 65536) {
       int done;
       if (b1 > 8 && b2 > 8) done = gap_sort_slots_impl<9, 9>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
@@ -1568,7 +1568,7 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   if (plain && c.lean_slots && !c.arena_on && c.lean_any_order && (text.fill_even || reach > 0.97 || text.fill == 0)) {
     const double avg = (double)n / ((double)n_buckets * reach);
     u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
-    if (c.lean_slots == 2) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
+    if (c.lean_slots == 2 || c.lean_slots == 5) s = avg < 1.0 ? 1 : (u64)avg;  // (tests: many buckets outgrow this)
     if (s <= cap && (u64)n_buckets * s < (1ull << 32) - (1ull << 20) &&
         (c.lean_slots > 1 || (double)n_buckets * (double)s * reach <= 1.25 * (double)n + 65536.0))
       slot = (u32)s;
@@ -1621,83 +1621,83 @@ int leaf_sort_text_lean(Ctx &c, DBuf<u64> (&elems)[2], size_t n, u32 cap, const 
   }
   DBuf<u8> digits;
   if (!first_done) {
-  counts = DBuf<u32>(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
-  if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
-  else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
-  if (shard && shard->parts > 1) {
-    // This GPU keeps a stretch of the first digit's values: the `part`-th of `parts` stretches that hold about the
-    // same number of suffixes each.  Every GPU counts the whole text and cuts the same way; nothing is exchanged.
-    DBuf<u32> per(c, dig1);
-    hipLaunchKernelGGL(k_row_sums, dim3(ceil_div(dig1, 4)), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk, dig1, per.get());
-    HIP_CHECK(hipGetLastError());
-    std::vector<u32> h(dig1);
-    HIP_CHECK(hipMemcpyAsync(h.data(), per.get(), dig1 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    std::vector<u64> cum(dig1 + 1, 0);
-    for (u32 d = 0; d < dig1; d++) cum[d + 1] = cum[d] + h[d];
-    auto cut = [&](int j) {  // first digit of part j: the first one at which j / parts of the suffixes lie below
-      if (j <= 0) return 0u;
-      if (j >= shard->parts) return nd1;
-      const u64 want = (u64)n * (u64)j / (u64)shard->parts;
-      u32 d = 0;
-      while (d < nd1 && cum[d] < want) d++;
-      return d;
-    };
-    shard->bounds.assign((size_t)shard->parts + 1, 0);
-    for (int j = 0; j <= shard->parts; j++) shard->bounds[(size_t)j] = cum[cut(j)];
-    const u32 lo = cut(shard->part), hi = cut(shard->part + 1);
-    shard->dig_lo = lo;
-    shard->dig_hi = hi;
-    first_rank = cum[lo];
-    kept = (size_t)(cum[hi] - cum[lo]);
-    shard->first_rank = first_rank;
-    shard->count = kept;
-    // (an empty share -- both of its cuts fall inside one heavy digit, which the next share takes -- keeps a digit
-    // value that no element has)
-    first.keep_lo = hi > lo ? lo : dig1;
-    first.keep_hi = hi > lo ? hi : dig1 + 1;
-    scan_lo = first.keep_lo;  // only the rows of the digits kept are scanned, and read
-    scan_hi = hi > lo ? hi : dig1;
-  } else if (shard) {
-    shard->first_rank = 0;
-    shard->count = n;
-    shard->bounds.assign(2, 0);
-    shard->bounds[1] = n;
-  }
-  if (text.run_span) {
-    // suffixes left out of the sort: what is kept is what the histogram counted
-    if (shard && shard->parts > 1) fail(BWT_HIP_EINTERNAL, "leaf sort: a share of a leaf with suffixes left out");
-    first.keep_lo = 0;
-    first.keep_hi = dig1;
-    u32 *d_kept = c.d_scalars + 12;
-    scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, d_kept);
-    HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_kept, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    kept = c.h_scalars[0];
-    if (shard) {
+    counts = DBuf<u32>(c, (size_t)(text.b1 > 8 ? 512 : 256) * nblk);
+    if (text.b1 > 8) lean_text_hist<9>(c, n, nblk, first, count_keys, counts.get());
+    else lean_text_hist<8>(c, n, nblk, first, count_keys, counts.get());
+    if (shard && shard->parts > 1) {
+      // This GPU keeps a stretch of the first digit's values: the `part`-th of `parts` stretches that hold about the
+      // same number of suffixes each.  Every GPU counts the whole text and cuts the same way; nothing is exchanged.
+      DBuf<u32> per(c, dig1);
+      hipLaunchKernelGGL(k_row_sums, dim3(ceil_div(dig1, 4)), dim3(256), 0, c.stream, (const u32 *)counts.get(), nblk, dig1, per.get());
+      HIP_CHECK(hipGetLastError());
+      std::vector<u32> h(dig1);
+      HIP_CHECK(hipMemcpyAsync(h.data(), per.get(), dig1 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      std::vector<u64> cum(dig1 + 1, 0);
+      for (u32 d = 0; d < dig1; d++) cum[d + 1] = cum[d] + h[d];
+      auto cut = [&](int j) {  // first digit of part j: the first one at which j / parts of the suffixes lie below
+        if (j <= 0) return 0u;
+        if (j >= shard->parts) return nd1;
+        const u64 want = (u64)n * (u64)j / (u64)shard->parts;
+        u32 d = 0;
+        while (d < nd1 && cum[d] < want) d++;
+        return d;
+      };
+      shard->bounds.assign((size_t)shard->parts + 1, 0);
+      for (int j = 0; j <= shard->parts; j++) shard->bounds[(size_t)j] = cum[cut(j)];
+      const u32 lo = cut(shard->part), hi = cut(shard->part + 1);
+      shard->dig_lo = lo;
+      shard->dig_hi = hi;
+      first_rank = cum[lo];
+      kept = (size_t)(cum[hi] - cum[lo]);
+      shard->first_rank = first_rank;
       shard->count = kept;
-      shard->bounds[1] = kept;
+      // (an empty share -- both of its cuts fall inside one heavy digit, which the next share takes -- keeps a digit
+      // value that no element has)
+      first.keep_lo = hi > lo ? lo : dig1;
+      first.keep_hi = hi > lo ? hi : dig1 + 1;
+      scan_lo = first.keep_lo;  // only the rows of the digits kept are scanned, and read
+      scan_hi = hi > lo ? hi : dig1;
+    } else if (shard) {
+      shard->first_rank = 0;
+      shard->count = n;
+      shard->bounds.assign(2, 0);
+      shard->bounds[1] = n;
     }
-  } else {
-    u32 *rows = counts.get() + (size_t)scan_lo * nblk;
-    scan_exclusive_u32(c, rows, rows, (size_t)(scan_hi - scan_lo) * nblk, nullptr);
-  }
-  const size_t room = kept > 0 ? kept : 1;
-  elems[1] = DBuf<u64>(c, room);
-  if (text.b2 <= 8 && !slot) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
-    digits = DBuf<u8>(c, room + 16);
-    first.next_digits = digits.get();
-    first.next_shift = 64 - text.b2;
-  }
-  if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, counts.get());
-  else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, counts.get());
-  // the second pass's tiles: those of what was kept, cut at the regions' ends (at most one short tile per region)
-  nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
-  tmap = DBuf<uint2>(c, nblk2);
-  if (slot) treg = DBuf<u32>(c, nblk2);
-  hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
-                     tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi, slot ? treg.get() : (u32 *)nullptr);
-  HIP_CHECK(hipGetLastError());
+    if (text.run_span) {
+      // suffixes left out of the sort: what is kept is what the histogram counted
+      if (shard && shard->parts > 1) fail(BWT_HIP_EINTERNAL, "leaf sort: a share of a leaf with suffixes left out");
+      first.keep_lo = 0;
+      first.keep_hi = dig1;
+      u32 *d_kept = c.d_scalars + 12;
+      scan_exclusive_u32(c, counts.get(), counts.get(), (size_t)dig1 * nblk, d_kept);
+      HIP_CHECK(hipMemcpyAsync(c.h_scalars, d_kept, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+      kept = c.h_scalars[0];
+      if (shard) {
+        shard->count = kept;
+        shard->bounds[1] = kept;
+      }
+    } else {
+      u32 *rows = counts.get() + (size_t)scan_lo * nblk;
+      scan_exclusive_u32(c, rows, rows, (size_t)(scan_hi - scan_lo) * nblk, nullptr);
+    }
+    const size_t room = kept > 0 ? kept : 1;
+    elems[1] = DBuf<u64>(c, room);
+    if (text.b2 <= 8 && !slot) {  // the second pass's digits as bytes on the side: its histogram reads a byte per element, not eight
+      digits = DBuf<u8>(c, room + 16);
+      first.next_digits = digits.get();
+      first.next_shift = 64 - text.b2;
+    }
+    if (text.b1 > 8) lean_text_scatter<9>(c, elems[1].get(), n, nblk, first, counts.get());
+    else lean_text_scatter<8>(c, elems[1].get(), n, nblk, first, counts.get());
+    // the second pass's tiles: those of what was kept, cut at the regions' ends (at most one short tile per region)
+    nblk2 = ceil_div(room, RS_TILE) + nd1 + 1;
+    tmap = DBuf<uint2>(c, nblk2);
+    if (slot) treg = DBuf<u32>(c, nblk2);
+    hipLaunchKernelGGL(k_lean_tiles, dim3(1), dim3(1024), 0, c.stream, (const u32 *)counts.get(), nblk, nd1, (u32)kept, tfirst.get(),
+                       tmap.get(), nblk2, rstart.get(), scan_lo, scan_hi, slot ? treg.get() : (u32 *)nullptr);
+    HIP_CHECK(hipGetLastError());
   }
   if (kept_out) *kept_out = kept;
   const size_t room = kept > 0 ? kept : 1;

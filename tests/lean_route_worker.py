@@ -37,6 +37,8 @@ def main():
         assert hists == 0 and passes >= 11 and counted == 0 and firsts == passes, (hists, passes, counted, firsts)
     elif mode == "2":  # every second pass void, then again with offsets (first passes: counted, the texts are too small for a sample)
         assert hists >= 11 and passes == 2 * hists and counted == hists, (hists, passes, counted)
+    elif mode == "5":  # slotted first passes, every second pass void and run again with offsets over the first pass's areas
+        assert hists >= 11 and passes == 2 * hists and counted == 0, (hists, passes, counted)
     elif mode == "4":  # every first pass void, then again after counting
         assert hists == 0 and counted == passes >= 11 and firsts == 2 * passes, (hists, passes, counted, firsts)
     else:  # small texts: the slots would cost far more memory than the elements

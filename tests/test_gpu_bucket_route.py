@@ -28,7 +28,7 @@ def test_wide_bucket_route_on_small_texts():
     assert "wide route ok" in r.stdout
 
 
-@pytest.mark.parametrize("slots", ["1", "3", "2", "4"])
+@pytest.mark.parametrize("slots", ["1", "3", "2", "4", "5"])
 def test_lean_bucket_route_on_small_texts(slots):
     """The route of windows between 2^29 and 2^31 suffixes (8-byte elements without the first pass's digit, two
     passes, 2^16 to 2^18 buckets), forced onto small texts.  slots: the second pass as it chooses itself (offsets
