@@ -1394,6 +1394,7 @@ static int gap_sort_slots_impl(Ctx &c, u32 *keys[2], size_t n, int low, int b1, 
   const u32 sub = c.slot_sub, na = nd1 * sub;
   const double avg1 = (double)n / (double)used_buckets * (double)ceil_div(used_buckets, nd1) / (double)sub;
   const u32 slot1 = c.lean_slots == 4 ? (u32)avg1 + 1 : (u32)(((u64)(avg1 + 8.0 * sqrt(avg1) + 4096.0 + 64.0) + 63) & ~63ull);  // (4: tests)
+  if ((u64)na * slot1 >= (1ull << 32) - (1ull << 20)) return 0;  // (32-bit indices)
   const u32 nblk2 = ceil_div(n, RS_TILE) + na + 1;
   DBuf<u32> mid(c, (size_t)na * slot1);
   DBuf<u32> fill1(c, na), fill2(c, (size_t)n_buckets + 1), tfirst(c, nd1 + 1), treg(c, nblk2);
@@ -1505,7 +1506,8 @@ void gap_sort_lean(Ctx &c, u32 *keys[2], size_t n, int low, int b1, int b2, u32 
     const double avg = (double)n / (double)used_buckets;
     u64 s = ((u64)(avg + 8.0 * sqrt(avg) + 64.0) + 63) & ~63ull;
     if (c.lean_slots == 2 || c.lean_slots == 5) s = avg < 1.0 ? 1 : (u64)avg;
-    if (((u64)used_buckets + 1) * s * 2 <= (u64)n * 4 && s < 65536) {
+    // (the kernels index both outputs with 32 bits)
+    if (((u64)used_buckets + 1) * s * 2 <= (u64)n * 4 && s < 65536 && ((u64)used_buckets + 1) * s < (1ull << 32) - (1ull << 20)) {
       int done;
       if (b1 > 8 && b2 > 8) done = gap_sort_slots_impl<9, 9>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
       else if (b2 > 8) done = gap_sort_slots_impl<8, 9>(c, keys, n, low, b1, b2, start, (u32)s, used_buckets);
