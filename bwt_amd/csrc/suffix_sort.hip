@@ -2398,6 +2398,7 @@ struct RunPlan {
   // occurs, a fifth symbol leaves four fifths of the key space empty at every digit, and the buckets that are used
   // overflow.  Every suffix that begins with it is then in the block.
   bool merge = false;
+  i64 longest = 0;  // the leaf's part of the longest listed run of one symbol
 };
 
 // out[0] += the positions of [a, b) that hold sym, out[1] += those that hold a smaller symbol (the terminator too)
@@ -2473,6 +2474,7 @@ static RunPlan plan_run_filter(Ctx &c, i64 a, i64 b) {
     }
   }
   rp.on = best >= 4096 && rp.sym != 0;
+  rp.longest = best;
   // No code of its own for a symbol that is rare (RunPlan::merge): only where the alphabet without it has 2^k symbols
   // (bit-field codes), the symbol is not the smallest (its place in a key is taken by the symbol below it) and all
   // symbols are below 128 (the key roll's byte arithmetic).
@@ -3046,16 +3048,17 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   if (b < c.n) {
     slack = (b - a) / 256;
     if (slack < 4096) slack = 4096;
-    // A long periodic stretch (a run of one symbol above all) that crosses the leaf's end keeps the leaf's suffixes
-    // inside it tied until the doubling depth h exceeds half of what is left of the stretch, and a round reads ranks
-    // up to 2h beyond a suffix: the window reaches that far from the start, instead of finding out after log2 of the
-    // slack rounds, twice.  (A text that is still arriving is scanned for stretches at its first merge only.)
+    // A long periodic stretch (a run of one symbol above all) that crosses the leaf's end, or ends less than its own
+    // length before it, keeps the leaf's suffixes inside it tied until the doubling depth h exceeds half of what is
+    // left of the stretch, and a round reads ranks up to 2h beyond a suffix: the window reaches that far from the
+    // start, instead of finding out after log2 of the slack rounds, twice.  (A text that is still arriving is scanned
+    // for stretches at its first merge only.)
     if (c.chunks.empty()) {
       ensure_run_table(c);
       const size_t cnt = c.n_runs;
       for (size_t i = 0; i < cnt; i++) {
         const i64 s0 = c.runs_host[i], e0 = c.runs_host[cnt + i];
-        if (s0 < b && e0 > b) {
+        if (s0 < b && e0 > a) {
           const i64 from = s0 > a ? s0 : a;
           const i64 want = (e0 - b) + (e0 - from) + 4096;
           if (want > slack) slack = want;
@@ -3073,6 +3076,9 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   const RunPlan rp = plan_run_filter(c, a, b);
   const bool repeats = window_has_long_repeats(c, a, (u64)(b - a), rp.on);
   if (repeats && c.dc_mode > 0) dc_state = 1;
+  // (a long run of one symbol is one tied group far beyond what the sample ranks are used for: that attempt would sort
+  // the window, look at its ties and give way to the doubling rounds, which then sort the window again)
+  if (dc_state == 1 && c.dc_mode == 1 && !c.dc.valid && rp.longest >= 4096) dc_state = -1;
   for (;;) {
     const i64 e = dc_state == 1 ? b : b + slack;
     // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it

@@ -61,7 +61,7 @@ def main():
             dt = time.perf_counter() - t0
             if k == 1:
                 print("%s n=%d leaves=%d: %.1f ms, decoded back with %d mismatches" % (name, n, leaves, dt * 1e3, blk.ibwt_mismatches()), flush=True)
-                for nm, (ms, _, calls) in sorted(ctx.timers().items(), key=lambda t: -t[1][0])[:7]:
+                for nm, (ms, _, calls) in sorted(ctx.timers().items(), key=lambda t: -t[1][0])[:18]:
                     if nm != "inverse_chains":
                         print("  %-34s %9.2f ms %5d" % (nm, ms, calls))
             blk.free()
