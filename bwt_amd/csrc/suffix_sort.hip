@@ -311,13 +311,39 @@ __global__ void k_comp_text(const u8 *__restrict__ T, u64 n, const u32 *__restri
 // `overflow` (the caller retries with a longer window); a position of the slack beyond the leaf is
 // retired with a key of its own, so that it leaves the active list.  Its rank is then arbitrary inside
 // its group, which is harmless: by the rule above nothing exact ever reads it.
+//
+// Runs of one symbol (jump != 0; runs: the list of Ctx::runs_exact, T: the text).  A suffix c^L X with L >= h stays tied
+// with every other such suffix until h exceeds L: log2 of the run's length rounds, each over all of the run's
+// suffixes.  From depth RUN_JUMP_MIN on, where every run that long is in the list with its exact end, they are taken
+// out of that in two rounds.  jump 1: the secondary key of such a suffix is its order among them as far as the
+// run decides it -- by L, shorter first where the symbol X begins with is smaller than c, longer first where it is
+// larger (all of the first kind before all of the second: the key of the runs' closed form, "Runs in closed form") --
+// and no rank is looked up; a group whose first h symbols are c holds only such suffixes (a shorter run would have
+// left it), so the keys of a group are all of this kind.  Groups are then of one L, and stay so.  jump 2, every round
+// after that one: a suffix whose run was that long (L >= h_jump, the depth of the round before) steps over what is
+// left of its run, secondary key = rank of X, whose first h symbols must lie inside the window like those of any
+// look-up -- whatever h has grown to: the members of its group are only known to agree on c^L.
 __global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64 n, u64 h_exact,
                            const u32 *__restrict__ pos, const u32 *__restrict__ grp, u32 M, u64 h,
-                           u64 *__restrict__ comp, u32 *__restrict__ pout, u32 *__restrict__ overflow) {
+                           u64 *__restrict__ comp, u32 *__restrict__ pout, u32 *__restrict__ overflow,
+                           int jump = 0, u64 h_jump = 0, const u32 *__restrict__ runs = nullptr, u32 n_runs = 0,
+                           const u8 *__restrict__ T = nullptr) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   u32 p = pos[k];
   u64 q = (u64)p + h;
+  if (jump) {
+    const u64 end = run1_end(runs, n_runs, p);
+    if (end >= (u64)p + h_jump) {  // L = end - p >= h_jump
+      if (jump == 1) {
+        const u32 L = (u32)(end - p), c = T[p], f = end < n ? T[end] : 0u;
+        comp[k] = ((u64)grp[k] << 32) | (f > c ? 0x80000000u + (0x7FFFFFFFu - L) : L);
+        pout[k] = p;
+        return;
+      }
+      q = end;
+    }
+  }
   u64 need = h > h_exact ? q + h : q + 1;  // end of the stretch that must lie inside the window
   u32 sec;
   if (e < n && need > e) {
@@ -1537,6 +1563,10 @@ struct RefineRounds {
   u32 M = 0;
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the list after the first round
   int round = 0;
+  // the step over long runs of one symbol (k_comp_isa): 0 not yet, 1 this round, 2 from then on; -1: not in these
+  // rounds (positions that are not text positions, no exact list of runs, switched off)
+  int jump = -1;
+  u64 h_jump = 0;  // the depth of the round that ordered them by the runs' lengths
 };
 
 // One round through the radix passes: the list ordered by (group, secondary key), groups split where the key
@@ -1558,8 +1588,15 @@ static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1) {
     hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, T, S.n, S.wl_pos, (const u32 *)dense.get(), M,
                        (u32)S.h, c.sym_bits, K1, ck0.get(), cp0.get());
   } else {
+    if (S.jump == 0 && S.h >= RUN_JUMP_MIN) {
+      S.jump = 1;
+      S.h_jump = S.h;
+    }
+    KernelTimer kt(c, S.jump == 1 ? "refine:k_comp_isa_run_lengths" : "refine:k_comp_isa", (double)M * 16);
     hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, (const u32 *)S.isa, S.a, S.b, S.e, S.n, S.h_exact,
-                       S.wl_pos, (const u32 *)dense.get(), M, S.h, ck0.get(), cp0.get(), d_overflow);
+                       S.wl_pos, (const u32 *)dense.get(), M, S.h, ck0.get(), cp0.get(), d_overflow, S.jump > 0 ? S.jump : 0, S.h_jump,
+                       (const u32 *)c.runs, c.n_runs, c.T);
+    if (S.jump == 1) S.jump = 2;
   }
   HIP_CHECK(hipGetLastError());
   dense.reset();
@@ -1596,6 +1633,8 @@ static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
   while (S.M > 0) {
     const u32 M = S.M;
     Phase ph(c, phase, (double)M * 8 * 32);
+    // (the rounds that step over runs of one symbol go through the radix passes: k_comp_isa)
+    if (S.jump >= 0 && S.h >= RUN_JUMP_MIN) tile_rounds = false, tile_retry = 1 << 30;
     if (tile_rounds) {
       // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
       DBuf<u32> tp(c, M), tg(c, M);
@@ -2284,6 +2323,8 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
       hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N, isa.get());
     hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(R.M, 256)), dim3(256), 0, c.stream, R.wl_pos, R.wl_grp, R.M, (u32)a, isa.get());
     HIP_CHECK(hipGetLastError());
+    // (long runs of one symbol are stepped over where the list of them is exact: Ctx::runs_exact)
+    if (c.run_jump && c.chunks.empty() && c.runs_valid && c.runs_exact && c.runs && c.n_runs) R.jump = 0;
     if (!doubling_rounds(c, R, "leaf_doubling_round")) return false;
   }
   LeafEmit<View> em;
