@@ -103,7 +103,7 @@ int bwt_hip_create(int device, bwt_hip_ctx **out) {
   if (const char *v = getenv("BWT_HIP_COMPACT")) c.compact_allowed = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_DEFER_BUCKETS")) c.defer_buckets = atoi(v) != 0;
   if (const char *v = getenv("BWT_HIP_RUN_TABLE")) c.run_table = atoi(v) != 0;
-  if (const char *v = getenv("BWT_HIP_RUN_JUMP")) c.run_jump = atoi(v) != 0;
+  if (const char *v = getenv("BWT_HIP_RUN_JUMP")) c.run_jump = atoi(v);
   if (const char *v = getenv("BWT_HIP_DC")) c.dc_mode = atoi(v);
   if (const char *v = getenv("BWT_HIP_LEAN_BASE")) c.lean_base = atoi(v) != 0;
   (void)device_scratch(device, nullptr);  // this GPU's address of the static scratch array, looked up while it is current

@@ -139,24 +139,6 @@ __device__ __forceinline__ u32 run_around(const u32 *__restrict__ runs, u32 n_ru
   return runs[2 * n_runs + lo - 1];
 }
 
-// A run of one symbol of this many symbols or more holds three whole aligned blocks of the scan that makes the list
-// (gap.hip), at least one of them scanned even at the end of the text: it is in the list, with exact bounds.
-constexpr u32 RUN_JUMP_MIN = 16384;
-
-// The end of the listed run of ONE symbol that holds position p, 0 if there is none (for lists whose stretches are in
-// order of position and do not overlap such runs: Ctx::runs_exact).
-__device__ __forceinline__ u64 run1_end(const u32 *__restrict__ runs, u32 n_runs, u64 p) {
-  u32 lo = 0, hi = n_runs;  // the last stretch that starts at or below p
-  while (lo < hi) {
-    const u32 mid = (lo + hi) / 2;
-    if ((u64)runs[mid] <= p) lo = mid + 1;
-    else hi = mid;
-  }
-  if (lo == 0 || runs[2 * n_runs + lo - 1] != 1u) return 0;
-  const u64 end = runs[n_runs + lo - 1];
-  return p < end ? end : 0;
-}
-
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  This
 // bijection gives every XCD one contiguous range of tiles, so that the runs that
 // neighbouring tiles append to the same digit's output region meet in one L2

@@ -614,12 +614,10 @@ void gap_prefix_grouped(Ctx &c, const u16 *words, const u32 *word_off, const u32
 // block, the smallest period p with T[i] = T[i+p] for every i of the block; the host joins neighbouring blocks of one
 // period; a thread per end extends the stretch by the same rule, 3 * RUN_BLOCK + 8 steps at most (a stretch between
 // scanned blocks ends within RUN_BLOCK + 8 of them; behind the last scanned block up to two blocks' worth of text is
-// left).  For comparisons the list only saves work: a stretch listed shorter than it is, or not at all, is read symbol
-// by symbol.  The doubling rounds' step over runs of one symbol needs more -- Ctx::runs_exact, set below.
+// left).  The list only saves work: a stretch listed shorter than it is, or not at all, is read symbol by symbol.
 // ----------------------------------------------------------------------------
 constexpr u32 RUN_BLOCK = 4096;
 constexpr u32 RUN_MAX = 1u << 16;  // listed stretches at most
-static_assert(RUN_JUMP_MIN >= 4 * RUN_BLOCK, "a run of RUN_JUMP_MIN symbols holds three whole blocks");
 
 // flags[block] = smallest period 1..RUN_PERIOD_MAX of the block, 0 if it has none; *found counts the blocks that have
 // one.  A wavefront per block, 64 symbols a lane (plus the 8 behind them: the text holds 64 bytes more behind the
@@ -683,7 +681,6 @@ void ensure_run_table(Ctx &c) {
   c.n_runs = 0;
   c.runs_host.clear();
   c.runs_valid = true;
-  c.runs_exact = false;
   const u32 n_blocks = c.n > 64 ? (u32)(((u64)c.n - 64) / RUN_BLOCK) : 0;
   if (!c.run_table || n_blocks == 0) return;
   Phase ph(c, "gap:run_table", (double)c.n);  // (named like a kernel: once per text, not a call of a merge's phases)
@@ -726,18 +723,6 @@ void ensure_run_table(Ctx &c) {
   c.sync();  // `first` is on the stack
   c.n_runs = count;
   c.runs_host = std::move(first);
-  // exact for the long runs of one symbol?  Nothing was dropped from the list, the starts are in order, and a run of
-  // one symbol of RUN_JUMP_MIN symbols or more (listed with its true bounds then: three whole blocks inside it) shares
-  // no position with the stretches next to it.
-  bool exact = count < RUN_MAX;
-  const std::vector<u32> &r = c.runs_host;
-  for (u32 i = 0; exact && i < count; i++) {
-    if (i + 1 < count && r[i + 1] <= r[i]) exact = false;
-    if (r[2 * (size_t)count + i] != 1 || r[(size_t)count + i] - r[i] < RUN_JUMP_MIN) continue;
-    if (i > 0 && r[(size_t)count + i - 1] > r[i]) exact = false;
-    if (i + 1 < count && r[i + 1] < r[(size_t)count + i]) exact = false;
-  }
-  c.runs_exact = exact;
 }
 
 // LF-mapping chains of the right positions [ra, rb) against the block l (ra >= l.b; the positions need

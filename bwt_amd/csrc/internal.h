@@ -143,11 +143,8 @@ struct Ctx {
   u32 n_runs = 0;
   std::vector<u32> runs_host;  // the same list on the host (the leaf sort sizes its window by it)
   bool runs_valid = false;
-  // every run of one symbol of RUN_JUMP_MIN symbols and more is in the list with its exact bounds, the list is in
-  // order of position and none of these runs overlaps another listed stretch (what the doubling rounds' step over
-  // such runs relies on: suffix_sort.hip, RefineRounds::jump)
-  bool runs_exact = false;
-  bool run_jump = true;  // off: the doubling rounds take runs of one symbol like anything else (tests)
+  bool window_long_run = false;  // the leaf window being sorted holds a listed run of one symbol of 4096 symbols or more
+  int run_jump = 1;  // 0: the doubling rounds take runs of one symbol like anything else, 2: step over them in every window (tests)
   bool run_table = true;  // off: comparisons read every symbol (tests)
   // large leaf windows are probed for long repeats before a bucket route or the direct pass is tried on them
   bool repeat_probe = true;

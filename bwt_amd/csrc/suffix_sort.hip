@@ -312,36 +312,65 @@ __global__ void k_comp_text(const u8 *__restrict__ T, u64 n, const u32 *__restri
 // retired with a key of its own, so that it leaves the active list.  Its rank is then arbitrary inside
 // its group, which is harmless: by the rule above nothing exact ever reads it.
 //
-// Runs of one symbol (jump != 0; runs: the list of Ctx::runs_exact, T: the text).  A suffix c^L X with L >= h stays tied
-// with every other such suffix until h exceeds L: log2 of the run's length rounds, each over all of the run's
-// suffixes.  From depth RUN_JUMP_MIN on, where every run that long is in the list with its exact end, they are taken
-// out of that in two rounds.  jump 1: the secondary key of such a suffix is its order among them as far as the
-// run decides it -- by L, shorter first where the symbol X begins with is smaller than c, longer first where it is
-// larger (all of the first kind before all of the second: the key of the runs' closed form, "Runs in closed form") --
-// and no rank is looked up; a group whose first h symbols are c holds only such suffixes (a shorter run would have
-// left it), so the keys of a group are all of this kind.  Groups are then of one L, and stay so.  jump 2, every round
-// after that one: a suffix whose run was that long (L >= h_jump, the depth of the round before) steps over what is
-// left of its run, secondary key = rank of X, whose first h symbols must lie inside the window like those of any
-// look-up -- whatever h has grown to: the members of its group are only known to agree on c^L.
+// Runs of one symbol (RunJump::state != 0).  A suffix c^L X with L >= h stays tied with every other such suffix until
+// h exceeds L: log2 of the run's length rounds, each over all of the run's suffixes.  Where a window holds long runs
+// the rounds take them out of that.
+// state 1, a round of its own before the first doubling round, at that round's depth h_jump, which it leaves as it is:
+// the group whose first h_jump symbols are c holds exactly the suffixes with L >= h_jump; it is cut into those with
+// L < 2 h_jump whose X begins with a smaller symbol than c (key 1), the long ones (L >= 2 h_jump) by what the run
+// decides of their order -- by L, shorter first where X begins with a smaller symbol than c, longer first where with a
+// larger one, all of the first kind before all of the second: the key of the runs' closed form, "Runs in closed form" --
+// and the short ones with a larger symbol behind the run (key 2^32 - 1): their true order.  Every other suffix keeps
+// its group (key 1 for all).  No rank is looked up.  All groups still agree on h_jump symbols, the long ones' on L.
+// state 2, the doubling rounds: a suffix with L >= max(h, 2 h_jump) steps over what is left of its run, secondary key
+// = rank of X (whose first h symbols must lie inside the window like those of any look-up).  Its group is of one L,
+// so all its members do the same, and what the round leaves tied agrees on L + h >= 2h symbols: the rounds' invariant.
+// A suffix whose run is shorter than h is looked up at p + h like any other.
+struct RunJump {
+  int state;          // 0: off
+  u64 h_jump;
+  const u32 *ends;    // ends[N - 1 - i] = N - i_end for the last position i_end >= i of the run that holds window index i,
+                      // 0 where the run reaches the window's last position (a maximum scan from the window's end)
+  u64 N, tail;        // window length; how far the run at the window's end goes on behind it
+  const u8 *T;
+  // what is left of the run from text position p = a + i on, p included
+  __device__ __forceinline__ u64 left(u64 i) const {
+    const u32 v = ends[N - 1 - i];
+    return v ? (N - v) - i + 1 : (N - i) + tail;
+  }
+};
+// the look-up position of the suffix at p in a round of depth h (*q = p + h on entry), or true: *sec_out is the key and
+// nothing is looked up
+__device__ __forceinline__ bool run_jump_key(const RunJump &J, u64 a, u64 n, u64 h, u32 p, u64 *q, u32 *sec_out) {
+  const u64 L = J.left((u64)p - a);
+  if (J.state == 1) {
+    u32 key = 1;
+    if (L >= J.h_jump) {
+      const u64 end = (u64)p + L;
+      const u32 c = J.T[p], f = end < n ? J.T[end] : 0u;
+      if (L >= 2 * J.h_jump) key = f > c ? 0x80000000u + (0x7FFFFFFEu - (u32)L) : 2u + (u32)L;
+      else key = f > c ? 0xFFFFFFFFu : 1u;
+    }
+    *sec_out = key;
+    return true;
+  }
+  if (L >= h && L >= 2 * J.h_jump) *q = (u64)p + L;
+  return false;
+}
+
 __global__ void k_comp_isa(const u32 *__restrict__ isa, u64 a, u64 b, u64 e, u64 n, u64 h_exact,
                            const u32 *__restrict__ pos, const u32 *__restrict__ grp, u32 M, u64 h,
-                           u64 *__restrict__ comp, u32 *__restrict__ pout, u32 *__restrict__ overflow,
-                           int jump = 0, u64 h_jump = 0, const u32 *__restrict__ runs = nullptr, u32 n_runs = 0,
-                           const u8 *__restrict__ T = nullptr) {
+                           u64 *__restrict__ comp, u32 *__restrict__ pout, u32 *__restrict__ overflow, RunJump J) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   u32 p = pos[k];
   u64 q = (u64)p + h;
-  if (jump) {
-    const u64 end = run1_end(runs, n_runs, p);
-    if (end >= (u64)p + h_jump) {  // L = end - p >= h_jump
-      if (jump == 1) {
-        const u32 L = (u32)(end - p), c = T[p], f = end < n ? T[end] : 0u;
-        comp[k] = ((u64)grp[k] << 32) | (f > c ? 0x80000000u + (0x7FFFFFFFu - L) : L);
-        pout[k] = p;
-        return;
-      }
-      q = end;
+  if (J.state) {
+    u32 key;
+    if (run_jump_key(J, a, n, h, p, &q, &key)) {
+      comp[k] = ((u64)grp[k] << 32) | key;
+      pout[k] = p;
+      return;
     }
   }
   u64 need = h > h_exact ? q + h : q + 1;  // end of the stretch that must lie inside the window
@@ -384,6 +413,7 @@ struct RefineTileParams {
   u32 *npos, *ngrp;  // per list entry, in the new order: position, new group name (the rank indices stay as they are)
   u8 *ntied;         // bit 0: still tied; bit 1: the group name changed (the inverse array needs it)
   u32 *wg_tied;      // per workgroup (zeroed by the caller): its entries that are still tied
+  RunJump J;         // runs of one symbol: see k_comp_isa
 };
 
 __global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) {
@@ -425,9 +455,13 @@ __global__ void __launch_bounds__(RT_THREADS) k_refine_tile(RefineTileParams P) 
     const u32 p = P.pos[base + i];
     Bp[i] = p;
     Ds[i] = P.slot[base + i];
-    const u64 q = (u64)p + P.h;
-    const u64 need = P.h > P.h_exact ? q + P.h : q + 1;
+    u64 q = (u64)p + P.h;
     u32 sec;
+    if (P.J.state && run_jump_key(P.J, P.a, P.n, P.h, p, &q, &sec)) {
+      Cs[i] = sec;
+      continue;
+    }
+    const u64 need = P.h > P.h_exact ? q + P.h : q + 1;
     if (P.e < P.n && need > P.e) {
       if (p < P.b) *P.overflow = 1;
       sec = 0xFFFFFFFFu - (u32)(p - P.a);
@@ -1563,16 +1597,16 @@ struct RefineRounds {
   u32 M = 0;
   DBuf<u32> nl_slot, nl_pos, nl_grp;  // owners of the list after the first round
   int round = 0;
-  // the step over long runs of one symbol (k_comp_isa): 0 not yet, 1 this round, 2 from then on; -1: not in these
-  // rounds (positions that are not text positions, no exact list of runs, switched off)
-  int jump = -1;
-  u64 h_jump = 0;  // the depth of the round that ordered them by the runs' lengths
+  // the step over long runs of one symbol (k_comp_isa): state 0 not in these rounds, 1 in the next round (the first
+  // doubling round), 2 from then on
+  RunJump J{0, 0, nullptr, 0, 0, nullptr};
+  DBuf<u32> run_ends;  // owner of J.ends
 };
 
 // One round through the radix passes: the list ordered by (group, secondary key), groups split where the key
 // changes.  T != null: a text round (secondary = the next K1 symbols at depth h); else a doubling round.  Returns
 // false when a doubling round had to look beyond the window.
-static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1) {
+static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1, bool keep_depth = false) {
   u32 *d_total = c.d_scalars + 8, *d_overflow = c.d_scalars + 9;
   const u32 M = S.M;
   const int gbits = bits_for(S.N);
@@ -1588,15 +1622,9 @@ static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1) {
     hipLaunchKernelGGL(k_comp_text, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, T, S.n, S.wl_pos, (const u32 *)dense.get(), M,
                        (u32)S.h, c.sym_bits, K1, ck0.get(), cp0.get());
   } else {
-    if (S.jump == 0 && S.h >= RUN_JUMP_MIN) {
-      S.jump = 1;
-      S.h_jump = S.h;
-    }
-    KernelTimer kt(c, S.jump == 1 ? "refine:k_comp_isa_run_lengths" : "refine:k_comp_isa", (double)M * 16);
+    KernelTimer kt(c, S.J.state == 1 ? "refine:k_comp_isa_run_lengths" : "refine:k_comp_isa", (double)M * 16);
     hipLaunchKernelGGL(k_comp_isa, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, (const u32 *)S.isa, S.a, S.b, S.e, S.n, S.h_exact,
-                       S.wl_pos, (const u32 *)dense.get(), M, S.h, ck0.get(), cp0.get(), d_overflow, S.jump > 0 ? S.jump : 0, S.h_jump,
-                       (const u32 *)c.runs, c.n_runs, c.T);
-    if (S.jump == 1) S.jump = 2;
+                       S.wl_pos, (const u32 *)dense.get(), M, S.h, ck0.get(), cp0.get(), d_overflow, S.J);
   }
   HIP_CHECK(hipGetLastError());
   dense.reset();
@@ -1616,6 +1644,7 @@ static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1) {
   S.wl_slot = S.nl_slot.get();
   S.wl_pos = S.nl_pos.get();
   S.wl_grp = S.nl_grp.get();
+  if (keep_depth) return true;  // (the round that cuts the groups of long runs: no look-ups, the depth stays)
   S.h = T ? S.h + (u64)K1 : 2 * S.h;
   S.round++;
   if (!T && read_u32(c, d_overflow)) return false;
@@ -1630,11 +1659,15 @@ static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
   u32 *d_total = c.d_scalars + 8, *d_overflow = c.d_scalars + 9, *d_fail = c.d_scalars + 10;
   bool tile_rounds = true;
   int tile_retry = 0;
+  if (S.J.state == 1 && S.M > 0) {  // long runs of one symbol: their groups are cut first (RunJump)
+    Phase ph(c, phase, (double)S.M * 8 * 32);
+    S.J.h_jump = S.h;
+    radix_round(c, S, nullptr, 0, true);
+    S.J.state = 2;
+  }
   while (S.M > 0) {
     const u32 M = S.M;
     Phase ph(c, phase, (double)M * 8 * 32);
-    // (the rounds that step over runs of one symbol go through the radix passes: k_comp_isa)
-    if (S.jump >= 0 && S.h >= RUN_JUMP_MIN) tile_rounds = false, tile_retry = 1 << 30;
     if (tile_rounds) {
       // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
       DBuf<u32> tp(c, M), tg(c, M);
@@ -1644,7 +1677,7 @@ static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
       HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(u32), c.stream));
       HIP_CHECK(hipMemsetAsync(wg_tied.get(), 0, (size_t)n_wg * sizeof(u32), c.stream));
       RefineTileParams P{S.wl_slot, S.wl_pos, S.wl_grp, M, S.isa, S.sa_w, S.a, S.b, S.e, S.n, S.h_exact, S.h,
-                         d_overflow, d_fail, tp.get(), tg.get(), tt.get(), wg_tied.get()};
+                         d_overflow, d_fail, tp.get(), tg.get(), tt.get(), wg_tied.get(), S.J};
       {
         KernelTimer kt(c, "refine:k_refine_tile", (double)M * 25);
         hipLaunchKernelGGL(k_refine_tile, dim3(n_wg), dim3(RT_THREADS), 0, c.stream, P);
@@ -2121,6 +2154,43 @@ static bool dc_pass_applies(Ctx &c, u64 N, u32 M, u32 max_group, int K0, bool re
   return c.dc.valid || repeats || (u64)M * 8 >= N;
 }
 
+// marks[j] = j + 1 where a run of one symbol ends at window index i = N - 1 - j (the symbol behind it differs, or the
+// text ends), 0 elsewhere: a maximum scan over j then says, for every i, where its run ends (RunJump::ends)
+__global__ void k_run_end_marks(const u8 *__restrict__ T, u64 a, u64 N, u64 n, u32 *__restrict__ marks) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const u64 p = a + (N - 1 - j);
+  marks[j] = (p + 1 >= n || T[p] != T[p + 1]) ? (u32)(j + 1) : 0u;
+}
+
+// *ext = how many positions from x0 on hold the symbol sym (x0 < n; the terminator's position never does).  One
+// workgroup: 2048 positions a step, and after every step that found nothing else a look at the list of long runs,
+// which says where the one around the position ends at the earliest (the list only shortens the way).
+__global__ void __launch_bounds__(256) k_run_tail(const u8 *__restrict__ T, u64 n, u64 x0, u32 sym, const u32 *__restrict__ runs,
+                                                  u32 n_runs, u32 *__restrict__ ext) {
+  __shared__ u32 first_s;
+  u64 p = x0;
+  for (;;) {
+    if (threadIdx.x == 0) first_s = 2048;
+    __syncthreads();
+    const u64 mine = p + 8 * threadIdx.x;
+    u32 first = 8;
+    for (int j = 7; j >= 0; j--)
+      if (!(mine + j + 1 < n && T[mine + j] == sym)) first = (u32)j;
+    if (first < 8) atomicMin(&first_s, 8 * threadIdx.x + first);
+    __syncthreads();
+    const u32 found = first_s;
+    __syncthreads();
+    if (found < 2048) {
+      if (threadIdx.x == 0) *ext = (u32)(p + found - x0);
+      return;
+    }
+    p += 2048;
+    u64 end = 0;
+    if (n_runs && run_around(runs, n_runs, p, &end) == 1 && end > p + 16) p = end - 8;
+  }
+}
+
 // Everything after the round-0 sort: tie list, refinement, emit.  sa_w: the writable positions (pairs
 // layout) or null; e_w: the writable elements (packed layout) or null.  scratch: 2N free 32-bit words for
 // the first active list; grp_buf: N more words (pairs: the unused value buffer).
@@ -2323,8 +2393,29 @@ static bool finish_window(Ctx &c, i64 a, i64 b, i64 e, u64 N, int K0, u64 sym_ma
       hipLaunchKernelGGL(k_isa_init, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, sa_w, (u32)a, (u32)N, isa.get());
     hipLaunchKernelGGL(k_isa_fix, dim3(ceil_div(R.M, 256)), dim3(256), 0, c.stream, R.wl_pos, R.wl_grp, R.M, (u32)a, isa.get());
     HIP_CHECK(hipGetLastError());
-    // (long runs of one symbol are stepped over where the list of them is exact: Ctx::runs_exact)
-    if (c.run_jump && c.chunks.empty() && c.runs_valid && c.runs_exact && c.runs && c.n_runs) R.jump = 0;
+    // a window with long runs of one symbol: the rounds step over them (k_comp_isa, RunJump)
+    if (c.run_jump && (c.window_long_run || c.run_jump == 2) && N < (1ull << 31)) {
+      u32 tail = 0;
+      if ((u64)e + 1 < (u64)c.n) {  // does the run at the window's end go on behind it, and how far?
+        u8 last[2];
+        HIP_CHECK(hipMemcpyAsync(last, c.T + e - 1, 2, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        if (last[0] == last[1]) {
+          u32 *d_ext = c.d_scalars + 38;
+          hipLaunchKernelGGL(k_run_tail, dim3(1), dim3(256), 0, c.stream, c.T, (u64)c.n, (u64)e, (u32)last[0],
+                             (const u32 *)(c.runs_valid ? c.runs : nullptr), c.runs_valid ? c.n_runs : 0u, d_ext);
+          HIP_CHECK(hipGetLastError());
+          tail = read_u32(c, d_ext);
+        }
+      }
+      if (N + tail < (1ull << 31)) {
+        R.run_ends = DBuf<u32>(c, N);
+        hipLaunchKernelGGL(k_run_end_marks, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, c.T, (u64)a, N, (u64)c.n, R.run_ends.get());
+        HIP_CHECK(hipGetLastError());
+        scan_inclusive_max_u32(c, R.run_ends.get(), R.run_ends.get(), (size_t)N);
+        R.J = RunJump{1, 0, R.run_ends.get(), N, tail, c.T};
+      }
+    }
     if (!doubling_rounds(c, R, "leaf_doubling_round")) return false;
   }
   LeafEmit<View> em;
@@ -3120,6 +3211,7 @@ static void run_leaf_sort(Ctx &c, i64 a, i64 b, const EmitParams *E, DBuf<u32> *
   // (a long run of one symbol is one tied group far beyond what the sample ranks are used for: that attempt would sort
   // the window, look at its ties and give way to the doubling rounds, which then sort the window again)
   if (dc_state == 1 && c.dc_mode == 1 && !c.dc.valid && rp.longest >= 4096) dc_state = -1;
+  c.window_long_run = rp.longest >= 4096;  // (the doubling rounds then step over runs: RunJump)
   for (;;) {
     const i64 e = dc_state == 1 ? b : b + slack;
     // a text that is still being uploaded: the window, and what the direct comparisons may read beyond it
