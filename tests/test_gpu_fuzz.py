@@ -58,3 +58,15 @@ def test_random_multi_rank_configurations(ctx):
         L, s_rank, e_rank, r, p, used = bwt_amd.pmbwt_multi([0] * world, T, th, ns, seg)
         assert (s_rank, e_rank) == info1 and (L == L1).all(), tag
         assert len(r) == len(r1) and (r == r1).all() and (p == p1).all(), tag
+
+
+def test_random_small_configurations_with_the_step_over_runs_forced():
+    """tools/fuzz_small.py in a process of its own with BWT_HIP_RUN_JUMP=2: the doubling rounds then step over the runs
+    of one symbol in every window (by themselves only in windows that hold a run of 4096 symbols or more), and the
+    generator's skewed, run and small-alphabet texts are full of short runs."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BWT_HIP_RUN_JUMP="2")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_small.py"), "250", "77"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz ok: 250 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
