@@ -1655,10 +1655,24 @@ static bool radix_round(Ctx &c, RefineRounds &S, const u8 *T, int K1, bool keep_
 // Doubling rounds until no suffix shares its group: inside the groups in LDS (k_refine_tile) while the groups are
 // short enough, through the radix passes otherwise.  False: a look-up went beyond the window (the caller retries with
 // a longer one).
+// *out = members of the longest group of the list (a group's members hold consecutive ranks from its name on, so its
+// last member knows)
+__global__ void k_max_group(const u32 *__restrict__ slot, const u32 *__restrict__ grp, u32 M, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 len = 0;
+  if (i < M) {
+    const u32 g = grp[i];
+    if (i + 1 == M || grp[i + 1] != g) len = slot[i] - g + 1u;
+  }
+  len = wave_reduce_max(len);
+  // (an add per wavefront on one word would take longer than the pass: only a wavefront that beats what is there adds)
+  if (lane_id() == 0 && len > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, len);
+}
+
 static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
   u32 *d_total = c.d_scalars + 8, *d_overflow = c.d_scalars + 9, *d_fail = c.d_scalars + 10;
-  bool tile_rounds = true;
-  int tile_retry = 0;
+  u32 *d_longest = c.d_scalars + 39;
+  bool groups_fit = false;  // every group fits a workgroup (groups only get shorter: once true, true for good)
   if (S.J.state == 1 && S.M > 0) {  // long runs of one symbol: their groups are cut first (RunJump)
     Phase ph(c, phase, (double)S.M * 8 * 32);
     S.J.h_jump = S.h;
@@ -1668,8 +1682,16 @@ static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
   while (S.M > 0) {
     const u32 M = S.M;
     Phase ph(c, phase, (double)M * 8 * 32);
-    if (tile_rounds) {
-      // the round inside the groups, in LDS; falls through to the radix passes when a group is too long
+    // Inside the groups, in LDS, when every group fits a workgroup (one that starts in a workgroup's RT_TILE entries
+    // must end within its RT_CAP); through the radix passes otherwise.  A pass over the list says how long the
+    // longest group is, until it fits (the kernel checks as well, and raises *fail where a group does not fit).
+    if (!groups_fit) {
+      HIP_CHECK(hipMemsetAsync(d_longest, 0, sizeof(u32), c.stream));
+      hipLaunchKernelGGL(k_max_group, dim3(ceil_div(M, 256)), dim3(256), 0, c.stream, (const u32 *)S.wl_slot, (const u32 *)S.wl_grp, M, d_longest);
+      HIP_CHECK(hipGetLastError());
+      groups_fit = read_u32(c, d_longest) <= (u32)(RT_CAP - RT_TILE);
+    }
+    if (groups_fit) {
       DBuf<u32> tp(c, M), tg(c, M);
       DBuf<u8> tt(c, M);
       const u32 n_wg = ceil_div(M, RT_TILE);
@@ -1717,10 +1739,7 @@ static bool doubling_rounds(Ctx &c, RefineRounds &S, const char *phase) {
         if (S.round > 80) fail(BWT_HIP_EINTERNAL, "suffix sort did not converge");
         continue;
       }
-      tile_rounds = false;  // long groups: the later rounds only have shorter ones, but a failed try costs a pass
-      tile_retry = S.round + 3;
-    } else if (S.round >= tile_retry) {
-      tile_rounds = true;
+      groups_fit = false;  // (not expected: the pass above said they fit)
     }
     if (!radix_round(c, S, nullptr, 0)) return false;
   }
